@@ -1,0 +1,120 @@
+/*
+ * mi_sa.h -- C ABI of the MI355X simulated-annealing engine (libmi_sa.so).
+ *
+ * This is the drop-in boundary for the anneal ("sampler") step of
+ * michal7kw/scRNA_seq_QAnnealing_Clustering.  The reference has NO native FFI for this path: its
+ * sampler calls are Python method calls on third-party D-Wave objects
+ *     sampler.sample_qubo(Q, ...)      /root/reference/Python_Functions/BQM_clustering.py:57,75,85,245,263,273
+ *     sampler.sample(bqm, ...)         /root/reference/Python_Functions/BQM_clustering.py:386
+ *     LeapHybridDQMSampler().sample_dqm(dqm, ...)   /root/reference/Python_Functions/DQM_clustering.py:45
+ * The nearest native analogue is dwave-neal's C entry point `general_simulated_annealing(states,
+ * energies, num_samples, h, coupler_starts, coupler_ends, coupler_weights, sweeps_per_beta,
+ * beta_schedule, seed, ...)` (un-vendored third party).  Each entry point
+ * below names the reference call it serves.  The Python class `MI355XSampler`
+ * (scrna_seq_qannealing_clustering_amd/sampler.py) binds these with ctypes and presents the dimod
+ * Sampler surface; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every array is caller-allocated HOST memory unless stated otherwise;
+ *     the library stages inputs into HBM once per problem and keeps results in HBM until fetched.
+ *   - return 0 (MI_OK) or a negative MI_E* code; mi_last_error() gives a thread-local message.
+ *   - one internal HIP stream per problem handle; calls on one handle are serialised by the caller.
+ *   - replica r of a run has GLOBAL id (replica_offset + r); the random stream of a replica depends
+ *     only on (seed, global id), so sharding replicas over GPUs does not change any replica's result.
+ *   - binary states are uint8 0/1, R x n row-major; Potts labels are uint16, R x n row-major.
+ */
+#ifndef MI_SA_H
+#define MI_SA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK            0
+#define MI_EINVAL       -1   /* bad argument */
+#define MI_ENODEV       -2   /* no usable gfx950 device */
+#define MI_EHIP         -3   /* HIP runtime error (see mi_last_error) */
+#define MI_ENOMEM       -4
+#define MI_EUNSUPPORTED -5   /* size / variant not built */
+#define MI_ESTATE       -6   /* call out of order (e.g. fetch before anneal) */
+
+#define MI_KIND_DENSE     1
+#define MI_KIND_CSR_RANK1 2
+#define MI_KIND_POTTS_CSR 3
+
+typedef struct mi_sa_problem mi_sa_problem;
+
+const char *mi_last_error(void);
+int mi_abi_version(void);
+int mi_device_count(int *out_count);
+/* name (<= len-1 chars), CU count and HBM bytes of a device */
+int mi_device_info(int device, char *name, int len, int *out_cus, uint64_t *out_hbm_bytes);
+
+/* ---- problems ------------------------------------------------------------------------------ */
+
+/* Dense binary model  E(x) = x^T Qs x + offset ; Qs n x n row-major SYMMETRIC fp32, diagonal =
+ * linear terms.  Serves sampler.sample_qubo(Q) for an arbitrary QUBO dict (BQM_clustering.py:57;
+ * QA_subsampling.py:42,56,65; other_tools.py:62) and sampler.sample(bqm) (BQM_clustering.py:386). */
+int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int device,
+                                   mi_sa_problem **out);
+
+/* Structured binary model E(x) = sum lin_i x_i + sum_{i<j} (c_pair + S_ij) x_i x_j + offset,
+ * S symmetric sparse in CSR (both directions stored).  This is exactly the shape of the reference's
+ * graph-partition QUBO (BQM_clustering.py:38-47: sparse cut term + 2*gamma on every pair). */
+int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                                       const float *lin, float c_pair, int n, double offset,
+                                       int device, mi_sa_problem **out);
+
+/* Potts / DQM model E(l) = lin_offset + sum_{u<v, l_u==l_v} (c_pair + S_uv), K cases per variable:
+ * the model clustering_dqm builds (DQM_clustering.py:29-43) and hands to sample_dqm (:45). */
+int mi_sa_problem_create_potts_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                                       float c_pair, int n, int K, double lin_offset, int device,
+                                       mi_sa_problem **out);
+
+int mi_sa_problem_destroy(mi_sa_problem *p);
+int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases, int *device);
+
+/* ---- the anneal (replaces the sampler call itself) ------------------------------------------- */
+
+/* R independent Metropolis chains x num_sweeps sweeps, one beta per sweep (betas[num_sweeps]).
+ * init: NULL (random initial states from the replica's own stream) or R x n host states
+ * (uint8 for binary kinds, uint16 labels for Potts).  resync_interval > 0 recomputes the cached
+ * fp32 local fields from the state every that many sweeps (0 = never).  Asynchronous: returns after
+ * enqueueing on the problem's stream; mi_sa_sync / mi_sa_fetch wait. */
+int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
+                 const double *betas, uint64_t seed, const void *init, int resync_interval);
+
+int mi_sa_sync(mi_sa_problem *p);
+
+/* Device time of the anneal kernel(s) of the last mi_sa_anneal on this handle, from HIP events
+ * recorded on the problem's stream around the launch (milliseconds); implies mi_sa_sync. */
+int mi_sa_last_kernel_ms(mi_sa_problem *p, float *out_ms);
+
+/* Copy results of the last run to host: states (R x n, uint8 or uint16 by kind; nullable),
+ * energies (R doubles, recomputed from the final state on device; nullable), stats (nullable):
+ * stats[0] proposals, stats[1] accepted moves, stats[2] Q/CSR bytes read by accepted moves. */
+int mi_sa_fetch(mi_sa_problem *p, void *out_states, double *out_energy, uint64_t *out_stats);
+
+/* Best replica of the last run (reduced on device): its local index, energy, and an order-preserving
+ * packed key  (sortable(float(E)) << 32) | global_replica_id  suitable for an integer MIN all-reduce
+ * across GPUs (RCCL has no MINLOC).  out_state (nullable) receives that replica's n states. */
+int mi_sa_best(mi_sa_problem *p, int *out_index, double *out_energy, uint64_t *out_key,
+               void *out_state);
+
+/* ---- one-shot conveniences (host in, host out) ---------------------------------------------- */
+
+int mi_sa_qubo_dense_f32(const float *Qs, int n, double offset, int R, int num_sweeps,
+                         const double *betas, uint64_t seed, const uint8_t *init,
+                         uint8_t *out_states, double *out_energy, uint64_t *out_stats, int device);
+
+/* Batched energy evaluation E_r = x_r^T Qs x_r + offset for R states (K4; f32-input MFMA when the
+ * batch is >= 32 states wide, VALU otherwise).  Serves SampleSet energy re-evaluation. */
+int mi_energy_dense_f32(const float *Qs, int n, const uint8_t *X, int R, double offset,
+                        double *out_energy, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SA_H */

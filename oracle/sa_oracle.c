@@ -1,0 +1,590 @@
+/*
+ * oracle/sa_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object.  The product (scrna_seq_qannealing_clustering_amd/) never links, imports or
+ * calls it; the product path fails loudly when its HIP library is missing.
+ *
+ * What is restated here, and from where:
+ *
+ *  (1) orc_sa_ising_neal  -- the simulated-annealing algorithm of dwave-neal
+ *      (`neal.SimulatedAnnealingSampler`, dwave-neal 0.5.x / dwave-samplers >= 1.0), the local
+ *      sampler a user of the reference substitutes for the D-Wave call at the boundary
+ *      /root/reference/Python_Functions/BQM_clustering.py:57,75,85,245,263,273.  neal is a
+ *      third-party dependency (requirements.txt:1 `dwave-ocean-sdk>=3.3.0`, a floor, not a pin)
+ *      that is NOT vendored in /root/reference and NOT installable offline, so its published
+ *      algorithm is restated from SURVEY.md section 8c ("sampler side"): Ising spins +-1,
+ *      cached flip energies, variables visited in index order, the 44.36142/beta skip
+ *      threshold, xorshift128+ consumed only on uphill proposals, energies recomputed at the
+ *      end.  PARITY UNPINNED against real neal: the reference holds no output of any sampler
+ *      (no tests, no captured SampleSet).  What pins this file is (a) the
+ *      known-answer energies / exact optima of SURVEY.md section 8c, reproduced in
+ *      tests/test_oracle_kat.py, and (b) brute force on small graphs.
+ *
+ *  (2) orc_sa_dense_philox / orc_sa_csr_rank1_philox / orc_potts_csr_philox -- the SAME Metropolis
+ *      chain, restated with the counter-based Philox4x32-10 stream and fp32 cached local fields
+ *      that the MI355X kernels use (DESIGN.md "Chain specification"), so that GPU and CPU agree
+ *      flip for flip (bit-exact states).  Independent restatement: nothing in csrc/ is included.
+ *
+ *  (3) orc_energy_*  -- fp64 energy evaluators (E = x^T Qs x + offset) and the cut-edge counter.
+ *  (4) orc_bruteforce_qubo -- exact optimum for n <= 26.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; fmaf only where written explicitly).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11).  Known-answer vectors checked in tests.               */
+/* ------------------------------------------------------------------------------------------ */
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Random word for (variable i, sweep s, global replica g, stream tag): DESIGN.md "RNG addressing".
+ * Four consecutive 64-variable slots share one Philox block so that a 64-lane wave needs one
+ * Philox evaluation per four slots. */
+static inline uint32_t chain_word(uint64_t seed, uint32_t i, uint32_t s, uint32_t g, uint32_t tag)
+{
+    uint32_t ctr[4], key[2], out[4];
+    ctr[0] = ((i >> 8) << 6) | (i & 63u);
+    ctr[1] = s;
+    ctr[2] = g;
+    ctr[3] = tag;
+    key[0] = (uint32_t)seed;
+    key[1] = (uint32_t)(seed >> 32);
+    orc_philox4x32_10(ctr, key, out);
+    return out[(i >> 6) & 3u];
+}
+
+uint32_t orc_chain_word(uint64_t seed, uint32_t i, uint32_t s, uint32_t g, uint32_t tag)
+{
+    return chain_word(seed, i, s, g, tag);
+}
+
+/* -ln(u), u = 2 - m in (0,1], m in [1,2) built from the top 23 bits of r.  Degree-7 polynomial for
+ * ln(1+t)/t on [sqrt(1/2)-1, sqrt(2)-1]; every operation is a single IEEE fp32 op or fmaf, so a
+ * GPU evaluating the same sequence returns the same bits. */
+float orc_neglog_u(uint32_t r)
+{
+    union { uint32_t u; float f; } cv;
+    cv.u = 0x3f800000u | (r >> 9);
+    float u = 2.0f - cv.f;                 /* exact */
+    cv.f = u;
+    int e = (int)(cv.u >> 23) - 127;
+    cv.u = (cv.u & 0x007fffffu) | 0x3f800000u;
+    float m = cv.f;
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float t = m - 1.0f;                    /* exact */
+    float p = -0x1.9f9af6p-4f;
+    p = fmaf(p, t, 0x1.4cd8dcp-3f);
+    p = fmaf(p, t, -0x1.61491cp-3f);
+    p = fmaf(p, t, 0x1.977bcp-3f);
+    p = fmaf(p, t, -0x1.ff611p-3f);
+    p = fmaf(p, t, 0x1.555a22p-2f);
+    p = fmaf(p, t, -0x1.00007cp-1f);
+    p = fmaf(p, t, 0x1.fffffep-1f);
+    float lnm = p * t;
+    return fmaf(-(float)e, 0x1.62e43p-1f, -lnm);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* (2a) dense fp32 chain, Philox stream -- mirror of kernel K1                                  */
+/* ------------------------------------------------------------------------------------------ */
+/* Qs: n x n row-major symmetric fp32, diagonal = linear terms.  E(x) = x^T Qs x + offset.
+ * Local field f_i = Qs_ii + sum_{j != i} 2 Qs_ij x_j ; flip delta dE_i = (1 - 2 x_i) f_i.
+ * temps[s] = (float)(1.0 / (double)betas[s]).  Proposal i at sweep s is accepted iff
+ *     dE_i < neglog_u(word(i, s, g, 0)) * temps[s]        (fp32 multiply, fp32 compare)
+ * Field (re)initialisation: f = diag; then for j ascending with x_j = 1: f_i += 2 Qs_ji (i != j).
+ * Returns 0.  out_states R x n (uint8 0/1), out_energy R doubles (fp64 re-evaluation + offset),
+ * out_stats[0] += proposals, out_stats[1] += accepted flips. */
+static void field_init_dense(const float *Qs, int n, const uint8_t *x, float *f)
+{
+    for (int i = 0; i < n; ++i) f[i] = Qs[(size_t)i * n + i];
+    for (int j = 0; j < n; ++j) {
+        if (!x[j]) continue;
+        const float *row = Qs + (size_t)j * n;
+        for (int i = 0; i < n; ++i) {
+            if (i == j) continue;
+            float q2 = row[i] + row[i];
+            f[i] = f[i] + q2;
+        }
+    }
+}
+
+int orc_sa_dense_philox(const float *Qs, int n, double offset, int R, uint32_t replica_offset,
+                        int num_sweeps, const double *betas, uint64_t seed, const uint8_t *init,
+                        int resync_interval, uint8_t *out_states, double *out_energy,
+                        uint64_t *out_stats)
+{
+    uint64_t tot_prop = 0, tot_acc = 0;
+    float *temps = (float *)malloc(sizeof(float) * (size_t)(num_sweeps > 0 ? num_sweeps : 1));
+    for (int s = 0; s < num_sweeps; ++s) temps[s] = (float)(1.0 / betas[s]);
+#pragma omp parallel for schedule(dynamic) reduction(+ : tot_prop, tot_acc)
+    for (int r = 0; r < R; ++r) {
+        uint32_t g = replica_offset + (uint32_t)r;
+        uint8_t *x = out_states + (size_t)r * n;
+        float *f = (float *)malloc(sizeof(float) * (size_t)n);
+        if (init) memcpy(x, init + (size_t)r * n, (size_t)n);
+        else
+            for (int i = 0; i < n; ++i) x[i] = (uint8_t)(chain_word(seed, (uint32_t)i, 0, g, 1) >> 31);
+        field_init_dense(Qs, n, x, f);
+        for (int s = 0; s < num_sweeps; ++s) {
+            float T = temps[s];
+            for (int i = 0; i < n; ++i) {
+                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s, g, 0)) * T;
+                float dE = x[i] ? -f[i] : f[i];
+                ++tot_prop;
+                if (dE < thr) {
+                    float sgn = x[i] ? -1.0f : 1.0f;
+                    const float *row = Qs + (size_t)i * n;
+                    for (int j = 0; j < n; ++j) {
+                        if (j == i) continue;
+                        float q2 = row[j] + row[j];
+                        f[j] = f[j] + sgn * q2;
+                    }
+                    x[i] ^= 1;
+                    ++tot_acc;
+                }
+            }
+            if (resync_interval > 0 && (s + 1) % resync_interval == 0) field_init_dense(Qs, n, x, f);
+        }
+        /* fp64 energy from scratch */
+        double E = 0.0;
+        for (int i = 0; i < n; ++i) {
+            if (!x[i]) continue;
+            const float *row = Qs + (size_t)i * n;
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j)
+                if (x[j]) acc += (double)row[j];
+            E += acc;
+        }
+        out_energy[r] = E + offset;
+        free(f);
+    }
+    free(temps);
+    if (out_stats) { out_stats[0] += tot_prop; out_stats[1] += tot_acc; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* (2b) CSR + uniform pair term chain -- mirror of kernel K2                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* Model: E(x) = sum_i lin_i x_i + sum_{i<j} (c + S_ij) x_i x_j + offset where S is sparse and
+ * symmetric (CSR: rowptr/col/val hold S_ij for every stored neighbour, both directions) and c is
+ * the uniform pair coefficient (2*gamma for BQM_clustering.py:46-47).  Local field
+ *     f_i = lin_i + sum_j S_ij x_j + c (s - x_i),   s = sum x.
+ * The kernel caches g_i = lin_i + sum_j S_ij x_j (fp32, updated per accepted flip on neighbours
+ * only) and the integer s; f_i = g_i + c * (float)(s - x_i)  (one fp32 multiply, one add). */
+static void field_init_csr(const int *rowptr, const int *col, const float *val, const float *lin,
+                           int n, const uint8_t *x, float *g, int *s_out)
+{
+    int s = 0;
+    for (int i = 0; i < n; ++i) g[i] = lin[i];
+    for (int j = 0; j < n; ++j) {
+        if (!x[j]) continue;
+        ++s;
+        for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) g[col[e]] = g[col[e]] + val[e];
+    }
+    *s_out = s;
+}
+
+int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val, const float *lin,
+                            float c_pair, int n, double offset, int R, uint32_t replica_offset,
+                            int num_sweeps, const double *betas, uint64_t seed, const uint8_t *init,
+                            int resync_interval, uint8_t *out_states, double *out_energy,
+                            uint64_t *out_stats)
+{
+    uint64_t tot_prop = 0, tot_acc = 0;
+    float *temps = (float *)malloc(sizeof(float) * (size_t)(num_sweeps > 0 ? num_sweeps : 1));
+    for (int s = 0; s < num_sweeps; ++s) temps[s] = (float)(1.0 / betas[s]);
+#pragma omp parallel for schedule(dynamic) reduction(+ : tot_prop, tot_acc)
+    for (int r = 0; r < R; ++r) {
+        uint32_t gid = replica_offset + (uint32_t)r;
+        uint8_t *x = out_states + (size_t)r * n;
+        float *g = (float *)malloc(sizeof(float) * (size_t)n);
+        int S = 0;
+        if (init) memcpy(x, init + (size_t)r * n, (size_t)n);
+        else
+            for (int i = 0; i < n; ++i) x[i] = (uint8_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) >> 31);
+        field_init_csr(rowptr, col, val, lin, n, x, g, &S);
+        for (int s = 0; s < num_sweeps; ++s) {
+            float T = temps[s];
+            for (int i = 0; i < n; ++i) {
+                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s, gid, 0)) * T;
+                float fi = g[i] + c_pair * (float)(S - (int)x[i]);
+                float dE = x[i] ? -fi : fi;
+                ++tot_prop;
+                if (dE < thr) {
+                    float sgn = x[i] ? -1.0f : 1.0f;
+                    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+                        g[col[e]] = g[col[e]] + sgn * val[e];
+                    S += x[i] ? -1 : 1;
+                    x[i] ^= 1;
+                    ++tot_acc;
+                }
+            }
+            if (resync_interval > 0 && (s + 1) % resync_interval == 0)
+                field_init_csr(rowptr, col, val, lin, n, x, g, &S);
+        }
+        double E = 0.0;
+        long cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!x[i]) continue;
+            ++cnt;
+            E += (double)lin[i];
+            double acc = 0.0;
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+                if (x[col[e]]) acc += (double)val[e];
+            E += 0.5 * acc;
+        }
+        E += (double)c_pair * 0.5 * (double)cnt * (double)(cnt - 1);
+        out_energy[r] = E + offset;
+        free(g);
+    }
+    free(temps);
+    if (out_stats) { out_stats[0] += tot_prop; out_stats[1] += tot_acc; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* (2c) Potts / DQM chain on CSR + uniform pair term -- mirror of kernel K3                     */
+/* ------------------------------------------------------------------------------------------ */
+/* Model (DQM_clustering.py:29-43 after its set_ overwrites):
+ *     E(l) = lin_offset + sum_{u<v, l_u == l_v} B_uv,  B_uv = c + S_uv  (S sparse: -2w - c on edges)
+ * State l_i in [0,K).  Proposal for variable i at sweep s: target label
+ *     b = (a + 1 + (word(i,s,g,2) mod (K-1))) mod K      (uniform over the K-1 other labels)
+ * dE = [h_i(b) + c*cnt_b] - [h_i(a) + c*(cnt_a - 1)],  h_i(q) = sum_{j in N(i), l_j == q} S_ij
+ * accepted iff dE < neglog_u(word(i,s,g,0)) * temps[s].  h is recomputed per proposal from the CSR
+ * row in stored order (fp32 adds in that order); cnt are integers. */
+int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, float c_pair, int n,
+                         int K, double lin_offset, int R, uint32_t replica_offset, int num_sweeps,
+                         const double *betas, uint64_t seed, const uint16_t *init,
+                         uint16_t *out_labels, double *out_energy, uint64_t *out_stats)
+{
+    uint64_t tot_prop = 0, tot_acc = 0;
+    float *temps = (float *)malloc(sizeof(float) * (size_t)(num_sweeps > 0 ? num_sweeps : 1));
+    for (int s = 0; s < num_sweeps; ++s) temps[s] = (float)(1.0 / betas[s]);
+#pragma omp parallel for schedule(dynamic) reduction(+ : tot_prop, tot_acc)
+    for (int r = 0; r < R; ++r) {
+        uint32_t gid = replica_offset + (uint32_t)r;
+        uint16_t *l = out_labels + (size_t)r * n;
+        int *cnt = (int *)calloc((size_t)K, sizeof(int));
+        if (init) memcpy(l, init + (size_t)r * n, sizeof(uint16_t) * (size_t)n);
+        else
+            for (int i = 0; i < n; ++i)
+                l[i] = (uint16_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) % (uint32_t)K);
+        for (int i = 0; i < n; ++i) cnt[l[i]]++;
+        for (int s = 0; s < num_sweeps; ++s) {
+            float T = temps[s];
+            for (int i = 0; i < n && K > 1; ++i) {
+                int a = l[i];
+                int b = (a + 1 + (int)(chain_word(seed, (uint32_t)i, (uint32_t)s, gid, 2) % (uint32_t)(K - 1))) % K;
+                float ha = 0.0f, hb = 0.0f;
+                for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+                    int lj = l[col[e]];
+                    if (lj == a) ha = ha + val[e];
+                    if (lj == b) hb = hb + val[e];
+                }
+                float ea = ha + c_pair * (float)(cnt[a] - 1);
+                float eb = hb + c_pair * (float)cnt[b];
+                float dE = eb - ea;
+                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s, gid, 0)) * T;
+                ++tot_prop;
+                if (dE < thr) {
+                    l[i] = (uint16_t)b;
+                    cnt[a]--;
+                    cnt[b]++;
+                    ++tot_acc;
+                }
+            }
+        }
+        double E = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+                if (col[e] > i && l[col[e]] == l[i]) E += (double)val[e];
+        for (int q = 0; q < K; ++q) E += (double)c_pair * 0.5 * (double)cnt[q] * (double)(cnt[q] - 1);
+        out_energy[r] = E + lin_offset;
+        free(cnt);
+    }
+    free(temps);
+    if (out_stats) { out_stats[0] += tot_prop; out_stats[1] += tot_acc; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* (1) neal restatement: Ising, fp64, xorshift128+, CSR adjacency                               */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { uint64_t s0, s1; } xs128p_t;
+
+static inline uint64_t xs128p_next(xs128p_t *st)
+{
+    uint64_t x = st->s0;
+    uint64_t const y = st->s1;
+    st->s0 = y;
+    x ^= x << 23;
+    st->s1 = x ^ y ^ (x >> 17) ^ (y >> 26);
+    return st->s1 + y;
+}
+
+/* states: num_samples x n int8 (+-1), in/out.  Adjacency in CSR (nbr_ptr, nbr, nbr_J): for every
+ * coupler (u,v,J) both u->v and v->u are stored, as neal builds its per-variable neighbour lists.
+ * beta_schedule has num_betas entries, each held for sweeps_per_beta sweeps.  One RNG stream is
+ * shared by all samples, which run sequentially (neal is single-threaded; reads are sequential).
+ * Returns the number of samples completed.  stats: [0] proposals, [1] accepted flips. */
+int orc_sa_ising_neal(int8_t *states, double *energies, int num_samples, int n, const double *h,
+                      const int *nbr_ptr, const int *nbr, const double *nbr_J, int sweeps_per_beta,
+                      const double *beta_schedule, int num_betas, uint64_t seed,
+                      uint64_t *out_stats)
+{
+    const double RANDMAX = (double)0xFFFFFFFFFFFFFFFFull;
+    xs128p_t rng;
+    rng.s0 = seed ? seed : 0xFFFFFFFFFFFFFFFFull;
+    rng.s1 = 0;
+    uint64_t prop = 0, acc = 0;
+    double *dE = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int smp = 0; smp < num_samples; ++smp) {
+        int8_t *st = states + (size_t)smp * n;
+        for (int v = 0; v < n; ++v) {
+            double en = h[v];
+            for (int e = nbr_ptr[v]; e < nbr_ptr[v + 1]; ++e) en += (double)st[nbr[e]] * nbr_J[e];
+            dE[v] = -2.0 * (double)st[v] * en;
+        }
+        for (int bi = 0; bi < num_betas; ++bi) {
+            double beta = beta_schedule[bi];
+            for (int sw = 0; sw < sweeps_per_beta; ++sw) {
+                double threshold = 44.36142 / beta;
+                for (int v = 0; v < n; ++v) {
+                    ++prop;
+                    if (dE[v] >= threshold) continue;
+                    int flip = 0;
+                    if (dE[v] <= 0.0) flip = 1;
+                    else {
+                        uint64_t rnd = xs128p_next(&rng);
+                        if (exp(-dE[v] * beta) * RANDMAX > (double)rnd) flip = 1;
+                    }
+                    if (flip) {
+                        double mult = 4.0 * (double)st[v];
+                        for (int e = nbr_ptr[v]; e < nbr_ptr[v + 1]; ++e)
+                            dE[nbr[e]] += mult * nbr_J[e] * (double)st[nbr[e]];
+                        st[v] = (int8_t)(-st[v]);
+                        dE[v] = -dE[v];
+                        ++acc;
+                    }
+                }
+            }
+        }
+        double E = 0.0;
+        for (int v = 0; v < n; ++v) {
+            E += h[v] * (double)st[v];
+            for (int e = nbr_ptr[v]; e < nbr_ptr[v + 1]; ++e)
+                if (nbr[e] > v) E += (double)st[v] * nbr_J[e] * (double)st[nbr[e]];
+        }
+        energies[smp] = E;
+    }
+    free(dE);
+    if (out_stats) { out_stats[0] += prop; out_stats[1] += acc; }
+    return num_samples;
+}
+
+/* Same algorithm specialised to a DENSE coupling matrix (every variable neighbours every other,
+ * as for BQM_clustering.py:46-47): J is n x n row-major symmetric with zero diagonal.  Used as the
+ * timed CPU baseline on the dense PBMC QUBO (no neighbour-index indirection, so it is at least as
+ * fast as neal's own list-of-vectors loop).  `threads` > 1 runs samples in parallel, each sample
+ * with its own xorshift stream seeded seed + sample (a documented deviation from neal's single
+ * stream, used only for the all-cores baseline). */
+int orc_sa_ising_neal_dense(int8_t *states, double *energies, int num_samples, int n,
+                            const double *h, const double *J, int sweeps_per_beta,
+                            const double *beta_schedule, int num_betas, uint64_t seed, int threads,
+                            uint64_t *out_stats)
+{
+    const double RANDMAX = (double)0xFFFFFFFFFFFFFFFFull;
+    uint64_t prop = 0, acc = 0;
+    xs128p_t shared;
+    shared.s0 = seed ? seed : 0xFFFFFFFFFFFFFFFFull;
+    shared.s1 = 0;
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+    omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic) reduction(+ : prop, acc) if (threads > 1)
+    for (int smp = 0; smp < num_samples; ++smp) {
+        xs128p_t local;
+        xs128p_t *rng = &shared;
+        if (threads > 1) {
+            local.s0 = (seed + (uint64_t)smp) ? (seed + (uint64_t)smp) : 0xFFFFFFFFFFFFFFFFull;
+            local.s1 = 0;
+            rng = &local;
+        }
+        int8_t *st = states + (size_t)smp * n;
+        double *dE = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int v = 0; v < n; ++v) {
+            double en = h[v];
+            const double *row = J + (size_t)v * n;
+            for (int u = 0; u < n; ++u) en += (double)st[u] * row[u];
+            dE[v] = -2.0 * (double)st[v] * en;
+        }
+        for (int bi = 0; bi < num_betas; ++bi) {
+            double beta = beta_schedule[bi];
+            for (int sw = 0; sw < sweeps_per_beta; ++sw) {
+                double threshold = 44.36142 / beta;
+                for (int v = 0; v < n; ++v) {
+                    ++prop;
+                    if (dE[v] >= threshold) continue;
+                    int flip = 0;
+                    if (dE[v] <= 0.0) flip = 1;
+                    else {
+                        uint64_t rnd = xs128p_next(rng);
+                        if (exp(-dE[v] * beta) * RANDMAX > (double)rnd) flip = 1;
+                    }
+                    if (flip) {
+                        double mult = 4.0 * (double)st[v];
+                        const double *row = J + (size_t)v * n;
+                        double keep = dE[v];
+                        for (int u = 0; u < n; ++u) dE[u] += mult * row[u] * (double)st[u];
+                        st[v] = (int8_t)(-st[v]);
+                        dE[v] = -keep;
+                        ++acc;
+                    }
+                }
+            }
+        }
+        double E = 0.0;
+        for (int v = 0; v < n; ++v) {
+            E += h[v] * (double)st[v];
+            const double *row = J + (size_t)v * n;
+            double a = 0.0;
+            for (int u = v + 1; u < n; ++u) a += row[u] * (double)st[u];
+            E += (double)st[v] * a;
+        }
+        energies[smp] = E;
+        free(dE);
+    }
+    if (out_stats) { out_stats[0] += prop; out_stats[1] += acc; }
+    return num_samples;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* (3) evaluators                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+void orc_energy_dense_f64(const float *Qs, int n, const uint8_t *X, int R, double offset,
+                          double *out)
+{
+    for (int r = 0; r < R; ++r) {
+        const uint8_t *x = X + (size_t)r * n;
+        double E = 0.0;
+        for (int i = 0; i < n; ++i) {
+            if (!x[i]) continue;
+            const float *row = Qs + (size_t)i * n;
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j)
+                if (x[j]) acc += (double)row[j];
+            E += acc;
+        }
+        out[r] = E + offset;
+    }
+}
+
+void orc_energy_dense_f64d(const double *Qs, int n, const uint8_t *X, int R, double offset,
+                           double *out)
+{
+    for (int r = 0; r < R; ++r) {
+        const uint8_t *x = X + (size_t)r * n;
+        double E = 0.0;
+        for (int i = 0; i < n; ++i) {
+            if (!x[i]) continue;
+            const double *row = Qs + (size_t)i * n;
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j)
+                if (x[j]) acc += row[j];
+            E += acc;
+        }
+        out[r] = E + offset;
+    }
+}
+
+/* number of edges (eu[k], ev[k]) whose endpoints carry different labels: the integer edge cut */
+void orc_cut_edges_u8(const int *eu, const int *ev, int m, const uint8_t *X, int n, int R,
+                      int64_t *out)
+{
+    for (int r = 0; r < R; ++r) {
+        const uint8_t *x = X + (size_t)r * n;
+        int64_t c = 0;
+        for (int k = 0; k < m; ++k) c += (x[eu[k]] != x[ev[k]]);
+        out[r] = c;
+    }
+}
+
+void orc_cut_edges_u16(const int *eu, const int *ev, int m, const uint16_t *L, int n, int R,
+                       int64_t *out)
+{
+    for (int r = 0; r < R; ++r) {
+        const uint16_t *l = L + (size_t)r * n;
+        int64_t c = 0;
+        for (int k = 0; k < m; ++k) c += (l[eu[k]] != l[ev[k]]);
+        out[r] = c;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* (4) exact optimum by Gray-code enumeration, n <= 26; Qs symmetric fp64                       */
+/* ------------------------------------------------------------------------------------------ */
+int orc_bruteforce_qubo(const double *Qs, int n, double offset, double *min_E, uint64_t *argmin,
+                        uint64_t *num_min, double *second_E)
+{
+    if (n < 1 || n > 26) return -1;
+    double f[26];
+    int x[26];
+    for (int i = 0; i < n; ++i) { f[i] = Qs[(size_t)i * n + i]; x[i] = 0; }
+    double E = 0.0, best = 0.0, second = INFINITY;
+    uint64_t bestmask = 0, nbest = 1, mask = 0;
+    const double tol = 1e-9;
+    uint64_t total = 1ull << n;
+    for (uint64_t k = 1; k < total; ++k) {
+        int i = __builtin_ctzll(k);
+        double d = x[i] ? -1.0 : 1.0;
+        E += d * f[i];
+        x[i] ^= 1;
+        mask ^= (1ull << i);
+        for (int j = 0; j < n; ++j)
+            if (j != i) f[j] += d * 2.0 * Qs[(size_t)i * n + j];
+        if (E < best - tol) {
+            second = best; best = E; bestmask = mask; nbest = 1;
+        } else if (fabs(E - best) <= tol) {
+            ++nbest;
+            if (mask < bestmask) bestmask = mask;
+        } else if (E < second - tol) {
+            second = E;
+        }
+    }
+    *min_E = best + offset;
+    *argmin = bestmask;
+    *num_min = nbest;
+    *second_E = second + offset;
+    return 0;
+}

@@ -1,0 +1,151 @@
+"""Thin object layer over the C ABI: one ``Problem`` = one model resident in HBM on one GPU."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+class Problem:
+    """A model uploaded to one MI355X.  ``anneal`` is asynchronous; ``fetch``/``best`` wait."""
+
+    def __init__(self, handle, kind, n, num_cases, device):
+        self._h = handle
+        self.kind = kind
+        self.n = n
+        self.num_cases = num_cases
+        self.device = device
+        self._last = None
+
+    # -- constructors ---------------------------------------------------------------------------
+    @classmethod
+    def dense(cls, Qs: np.ndarray, offset: float = 0.0, device: int = 0) -> "Problem":
+        """``E(x) = x^T Qs x + offset`` with Qs symmetric (diag = linear terms)."""
+        Qs = np.ascontiguousarray(Qs, dtype=np.float32)
+        if Qs.ndim != 2 or Qs.shape[0] != Qs.shape[1]:
+            raise ValueError("Qs must be a square matrix")
+        if not np.array_equal(Qs, Qs.T):
+            raise ValueError("Qs must be symmetric (use (Q + Q.T)/2 with the diagonal kept)")
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.mi_sa_problem_create_dense_f32(_ptr(Qs, C.c_float), Qs.shape[0],
+                                                      float(offset), int(device), C.byref(h)))
+        return cls(h, _lib.KIND_DENSE, Qs.shape[0], 2, device)
+
+    @classmethod
+    def csr_rank1(cls, rowptr, col, val, lin, c_pair: float, offset: float = 0.0,
+                  device: int = 0) -> "Problem":
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        lin = np.ascontiguousarray(lin, dtype=np.float32)
+        n = len(lin)
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.mi_sa_problem_create_csr_rank1_f32(
+            _ptr(rowptr, C.c_int32), _ptr(col, C.c_int32), _ptr(val, C.c_float),
+            _ptr(lin, C.c_float), float(c_pair), n, float(offset), int(device), C.byref(h)))
+        return cls(h, _lib.KIND_CSR_RANK1, n, 2, device)
+
+    @classmethod
+    def potts_csr(cls, rowptr, col, val, c_pair: float, n: int, num_cases: int,
+                  lin_offset: float = 0.0, device: int = 0) -> "Problem":
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.mi_sa_problem_create_potts_csr_f32(
+            _ptr(rowptr, C.c_int32), _ptr(col, C.c_int32), _ptr(val, C.c_float), float(c_pair),
+            int(n), int(num_cases), float(lin_offset), int(device), C.byref(h)))
+        return cls(h, _lib.KIND_POTTS_CSR, int(n), int(num_cases), device)
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if self._h is not None and self._h.value:
+            _lib.load().mi_sa_problem_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the anneal -----------------------------------------------------------------------------
+    @property
+    def state_dtype(self):
+        return np.uint16 if self.kind == _lib.KIND_POTTS_CSR else np.uint8
+
+    def anneal(self, num_reads: int, betas, seed: int, replica_offset: int = 0,
+               initial_states: Optional[np.ndarray] = None, resync_interval: int = 0):
+        betas = np.ascontiguousarray(betas, dtype=np.float64)
+        init = None
+        if initial_states is not None:
+            init = np.ascontiguousarray(initial_states, dtype=self.state_dtype)
+            if init.shape != (num_reads, self.n):
+                raise ValueError("initial_states must have shape (num_reads, n) = (%d, %d)"
+                                 % (num_reads, self.n))
+        _lib.check(_lib.load().mi_sa_anneal(
+            self._h, int(num_reads), C.c_uint32(int(replica_offset) & 0xFFFFFFFF), len(betas),
+            _ptr(betas, C.c_double), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+            init.ctypes.data_as(C.c_void_p) if init is not None else None, int(resync_interval)))
+        self._last = (int(num_reads), len(betas))
+
+    def sync(self):
+        _lib.check(_lib.load().mi_sa_sync(self._h))
+
+    def kernel_ms(self) -> float:
+        ms = C.c_float(0.0)
+        _lib.check(_lib.load().mi_sa_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def fetch(self, states: bool = True, energies: bool = True):
+        if self._last is None:
+            raise RuntimeError("fetch() before anneal()")
+        R = self._last[0]
+        st = np.empty((R, self.n), dtype=self.state_dtype) if states else None
+        en = np.empty(R, dtype=np.float64) if energies else None
+        stats = np.zeros(3, dtype=np.uint64)
+        _lib.check(_lib.load().mi_sa_fetch(
+            self._h, st.ctypes.data_as(C.c_void_p) if st is not None else None,
+            _ptr(en, C.c_double), _ptr(stats, C.c_uint64)))
+        info = {"proposals": int(R) * int(self._last[1]) * int(self.n),
+                "accepted": int(stats[1]), "row_bytes": int(stats[2])}
+        return st, en, info
+
+    def best(self, want_state: bool = True):
+        idx = C.c_int(0)
+        en = C.c_double(0.0)
+        key = C.c_uint64(0)
+        st = np.empty(self.n, dtype=self.state_dtype) if want_state else None
+        _lib.check(_lib.load().mi_sa_best(
+            self._h, C.byref(idx), C.byref(en), C.byref(key),
+            st.ctypes.data_as(C.c_void_p) if st is not None else None))
+        return int(idx.value), float(en.value), int(key.value), st
+
+
+def energy_dense(Qs: np.ndarray, X: np.ndarray, offset: float = 0.0, device: int = 0) -> np.ndarray:
+    """Batched ``E_r = x_r^T Qs x_r + offset`` on the GPU (kernel K4)."""
+    Qs = np.ascontiguousarray(Qs, dtype=np.float32)
+    X = np.ascontiguousarray(X, dtype=np.uint8)
+    if X.ndim != 2 or X.shape[1] != Qs.shape[0]:
+        raise ValueError("X must have shape (R, n)")
+    out = np.empty(X.shape[0], dtype=np.float64)
+    _lib.check(_lib.load().mi_energy_dense_f32(_ptr(Qs, C.c_float), Qs.shape[0], _ptr(X, C.c_uint8),
+                                               X.shape[0], float(offset), _ptr(out, C.c_double),
+                                               int(device)))
+    return out

@@ -1,0 +1,402 @@
+"""Model builders: SNN graph -> graph-partition QUBO / Potts-DQM in array form.
+
+These are the host-side counterparts of the reference's in-line Python model construction
+(SURVEY.md section 8a rows A1-A4).  The reference accumulates a ``defaultdict`` of n(n+1)/2 Python
+floats (`/root/reference/Python_Functions/BQM_clustering.py:36-47`) or O(n^2 K) ``set_quadratic``
+dicts (`DQM_clustering.py:36-43`); here the same coefficients are produced directly as numpy arrays
+in the layouts the HIP kernels consume (dense symmetric ``Qs`` and/or CSR sparse part + uniform pair
+coefficient), so nothing quadratic in n is ever built in interpreted Python.
+
+Array convention (used everywhere): ``Qs`` is the symmetrised n x n matrix, ``Qs[i,i] = Q[i,i]``,
+``Qs[i,j] = Qs[j,i] = (Q[i,j] + Q[j,i]) / 2``; then ``E(x) = x^T Qs x + offset`` for binary x.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, Hashable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------
+# graph -> arrays
+# --------------------------------------------------------------------------------------------
+def graph_arrays(G) -> Tuple[List[Hashable], np.ndarray, np.ndarray, np.ndarray]:
+    """``(nodes, eu, ev, w)`` from a networkx graph, in ``G.nodes`` / ``G.edges`` order -- the orders
+    the reference's loops iterate in (BQM_clustering.py:38,43,46; DQM_clustering.py:30,36,40)."""
+    nodes = list(G.nodes)
+    index = {v: i for i, v in enumerate(nodes)}
+    m = G.number_of_edges()
+    eu = np.empty(m, dtype=np.int32)
+    ev = np.empty(m, dtype=np.int32)
+    w = np.empty(m, dtype=np.float64)
+    for k, (u, v, data) in enumerate(G.edges(data=True)):
+        eu[k] = index[u]
+        ev[k] = index[v]
+        w[k] = data["weight"]
+    return nodes, eu, ev, w
+
+
+def _graph_total_weight(G, w: np.ndarray) -> float:
+    """``G.size(weight="weight")`` (BQM_clustering.py:29).  networkx computes it as
+    ``sum(degree(weight)) / 2``; call it when available so gamma is bit-identical."""
+    try:
+        return float(G.size(weight="weight"))
+    except Exception:  # plain edge-list objects
+        return float(np.sum(w))
+
+
+def _csr_from_edges(n: int, eu: np.ndarray, ev: np.ndarray, val: np.ndarray):
+    """Symmetric CSR (both directions stored), neighbours in ascending column order, duplicate
+    (u,v) pairs summed.  Returns (rowptr int32[n+1], col int32[nnz], val float64[nnz])."""
+    rows = np.concatenate([eu, ev]).astype(np.int64)
+    cols = np.concatenate([ev, eu]).astype(np.int64)
+    vals = np.concatenate([val, val]).astype(np.float64)
+    keep = rows != cols
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    key = rows * n + cols
+    order = np.argsort(key, kind="stable")
+    key, vals = key[order], vals[order]
+    uniq, start = np.unique(key, return_index=True)
+    summed = np.add.reduceat(vals, start) if len(vals) else vals
+    r = (uniq // n).astype(np.int32)
+    c = (uniq % n).astype(np.int32)
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(rowptr, r + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    return rowptr, c, summed
+
+
+@dataclass
+class QuboModel:
+    """Binary quadratic model in array form.  ``E(x) = sum_i lin_i x_i + sum_{i<j} (c_pair + S_ij) x_i x_j
+    + offset`` with S sparse (CSR, both directions, holding the *upper-triangular coefficient* of the
+    pair, i.e. ``Q[i,j] + Q[j,i] - c_pair``).  ``dense_Qs()`` expands to the symmetric n x n form."""
+    variables: List[Hashable]
+    lin: np.ndarray                      # float64[n]   Q[i,i]
+    rowptr: np.ndarray                   # int32[n+1]
+    col: np.ndarray                      # int32[nnz]
+    val: np.ndarray                      # float64[nnz] pair coefficient minus c_pair
+    c_pair: float = 0.0                  # uniform coefficient on every pair i<j
+    offset: float = 0.0
+    info: Dict[str, Any] = field(default_factory=dict)
+    _dense: Optional[np.ndarray] = None  # set when the model was given densely (general Q)
+
+    @property
+    def num_variables(self) -> int:
+        return len(self.variables)
+
+    def dense_Qs(self, dtype=np.float64) -> np.ndarray:
+        if self._dense is not None:
+            return self._dense.astype(dtype, copy=False)
+        n = self.num_variables
+        Qs = np.full((n, n), 0.5 * self.c_pair, dtype=np.float64)
+        rows = np.repeat(np.arange(n), np.diff(self.rowptr))
+        Qs[rows, self.col] += 0.5 * self.val
+        Qs[np.arange(n), np.arange(n)] = self.lin
+        return Qs.astype(dtype, copy=False)
+
+    def to_qubo_dict(self) -> Dict[Tuple[Hashable, Hashable], float]:
+        """Upper-triangular dict form (small n only) -- the type the reference hands to
+        ``sampler.sample_qubo`` (BQM_clustering.py:57)."""
+        Qs = self.dense_Qs()
+        v = self.variables
+        n = len(v)
+        out = {}
+        for i in range(n):
+            out[(v[i], v[i])] = float(Qs[i, i])
+            for j in range(i + 1, n):
+                c = 2.0 * float(Qs[i, j])
+                if c != 0.0:
+                    out[(v[i], v[j])] = c
+        return out
+
+    def energies(self, X: np.ndarray) -> np.ndarray:
+        """fp64 energies of states X (R x n, 0/1) using the structured form (no n^2 work)."""
+        X = np.asarray(X)
+        Xf = X.astype(np.float64)
+        if self._dense is not None:
+            return np.einsum("ri,ri->r", Xf @ self._dense, Xf) + self.offset
+        s = Xf.sum(axis=1)
+        e = Xf @ self.lin + self.c_pair * 0.5 * s * (s - 1.0) + self.offset
+        rows = np.repeat(np.arange(self.num_variables), np.diff(self.rowptr))
+        e += 0.5 * np.einsum("re,re,e->r", Xf[:, rows], Xf[:, self.col], self.val)
+        return e
+
+
+def _cut_qubo_parts(n, eu, ev, w, k):
+    """Per-edge ``Q[u,u]+=k w; Q[v,v]+=k w; Q[u,v]+=-2 k w`` (BQM_clustering.py:38-41, :230-233,
+    :366-369) as (lin, pair-coefficient per edge)."""
+    lin = np.zeros(n, dtype=np.float64)
+    np.add.at(lin, eu, k * w)
+    np.add.at(lin, ev, k * w)
+    return lin, k * -2 * w
+
+
+def build_bqm_qubo(G, gamma_factor: float, k: float = 8) -> QuboModel:
+    """A1 -- `clustering_bqm` model, BQM_clustering.py:29-47:
+    ``gamma = gamma_factor * W / n``; cut term with ``k = 8`` (:33); ``Q[i,i] += gamma (1 - n)``
+    (:43-44); ``Q[i,j] += 2 gamma`` for every pair (:46-47).  Closed form
+    ``E = k cut_w + gamma (s^2 - n s)``."""
+    nodes, eu, ev, w = graph_arrays(G)
+    n = len(nodes)
+    W = _graph_total_weight(G, w)
+    gamma = gamma_factor * W / n
+    lin, pair = _cut_qubo_parts(n, eu, ev, w, k)
+    lin = lin + gamma * (1 - n)
+    rowptr, col, val = _csr_from_edges(n, eu, ev, pair)
+    return QuboModel(nodes, lin, rowptr, col, val, c_pair=2 * gamma, offset=0.0,
+                     info={"gamma": gamma, "k": k, "W": W, "kind": "bqm"})
+
+
+def build_bqm2_qubo(G, gamma_factor: float, k: float) -> QuboModel:
+    """A2 -- `clustering_bqm_2` model, BQM_clustering.py:210-236: ``gamma = (W / n) gamma_factor``
+    (:222), cut term with caller's k (:230-233), linear-only penalty ``Q[i,i] += gamma`` (:235-236);
+    also the QPU-only ``chain_strength = mean(w) mean(deg) 2`` (:212-220) for reporting."""
+    nodes, eu, ev, w = graph_arrays(G)
+    n = len(nodes)
+    W = _graph_total_weight(G, w)
+    gamma = (W / n) * gamma_factor
+    lin, pair = _cut_qubo_parts(n, eu, ev, w, k)
+    lin = lin + gamma
+    rowptr, col, val = _csr_from_edges(n, eu, ev, pair)
+    deg = np.zeros(n, dtype=np.int64)
+    np.add.at(deg, eu, 1)
+    np.add.at(deg, ev, 1)
+    chain_strength = float(np.mean(w)) * float(np.mean(deg)) * 2 if len(w) else 0.0
+    return QuboModel(nodes, lin, rowptr, col, val, c_pair=0.0, offset=0.0,
+                     info={"gamma": gamma, "k": k, "W": W, "chain_strength": chain_strength,
+                           "kind": "bqm_2"})
+
+
+def build_bqm3_cut_qubo(G, k: float = 8) -> QuboModel:
+    """A3 (QUBO part) -- `clustering_bqm_3`, BQM_clustering.py:363-369: cut term only.  The slack
+    inequality of :373-380 is added by ``add_size_window_penalty``."""
+    nodes, eu, ev, w = graph_arrays(G)
+    n = len(nodes)
+    lin, pair = _cut_qubo_parts(n, eu, ev, w, k)
+    rowptr, col, val = _csr_from_edges(n, eu, ev, pair)
+    return QuboModel(nodes, lin, rowptr, col, val, c_pair=0.0, offset=0.0,
+                     info={"k": k, "kind": "bqm_3"})
+
+
+# --------------------------------------------------------------------------------------------
+# Potts / DQM
+# --------------------------------------------------------------------------------------------
+@dataclass
+class PottsModel:
+    """k-way model ``E(l) = lin_offset + sum_{u<v, l_u == l_v} (c_pair + S_uv)`` -- the form
+    `clustering_dqm` (DQM_clustering.py:29-43) reduces to after its ``set_`` overwrites: the linear
+    biases are case-independent (a constant under one-hot) and every pair couples equal cases only."""
+    variables: List[Hashable]
+    num_cases: int
+    rowptr: np.ndarray
+    col: np.ndarray
+    val: np.ndarray                      # float64[nnz]  B_uv - c_pair on stored pairs
+    c_pair: float
+    lin: np.ndarray                      # float64[n]    case-independent linear bias per variable
+    info: Dict[str, Any] = field(default_factory=dict)
+
+    @property
+    def num_variables(self) -> int:
+        return len(self.variables)
+
+    @property
+    def lin_offset(self) -> float:
+        return float(np.sum(self.lin))
+
+    def energies(self, L: np.ndarray) -> np.ndarray:
+        L = np.asarray(L).astype(np.int64)
+        R, n = L.shape
+        rows = np.repeat(np.arange(n), np.diff(self.rowptr))
+        same = (L[:, rows] == L[:, self.col])
+        e = 0.5 * (same * self.val[None, :]).sum(axis=1)
+        for r in range(R):
+            cnt = np.bincount(L[r], minlength=self.num_cases).astype(np.float64)
+            e[r] += self.c_pair * 0.5 * float(np.sum(cnt * (cnt - 1.0)))
+        return e + self.lin_offset
+
+
+def build_dqm_potts(G, num_of_clusters: int, gamma: float) -> PottsModel:
+    """A4 -- `clustering_dqm` model, DQM_clustering.py:29-43, in Potts form.
+
+    After the reference's overwrites: ``lin[v][c]`` = weight of the LAST edge in ``G.edges`` order
+    touching v (:42-43), or ``gamma (1 - n/K)`` for isolated nodes (:33-34); pair bias on equal cases
+    ``-2 w_uv`` on edges (:41, overwriting the ``2 gamma`` of :36-37), ``2 gamma`` elsewhere."""
+    nodes, eu, ev, w = graph_arrays(G)
+    n = len(nodes)
+    K = int(num_of_clusters)
+    lin = np.full(n, gamma * (1 - n / K), dtype=np.float64)
+    for a, b, ww in zip(eu.tolist(), ev.tolist(), w.tolist()):   # order matters: last write wins
+        lin[a] = ww
+        lin[b] = ww
+    # pair bias on an edge is SET to -2w (last edge wins if a pair repeats; nx.Graph has no repeats)
+    pair = -2.0 * w - 2.0 * gamma
+    rowptr, col, val = _csr_from_edges(n, eu, ev, pair)
+    return PottsModel(nodes, K, rowptr, col, val, c_pair=2.0 * gamma, lin=lin,
+                      info={"gamma": gamma, "kind": "dqm"})
+
+
+# --------------------------------------------------------------------------------------------
+# generic Q dict -> arrays (any caller of sample_qubo: QA_subsampling.py:28-35, other_tools.py:62 ...)
+# --------------------------------------------------------------------------------------------
+def qubo_dict_to_model(Q: Dict[Tuple[Hashable, Hashable], float], offset: float = 0.0,
+                       detect_uniform: bool = True) -> QuboModel:
+    """Lift a dimod-style QUBO dict into array form.  Variable order = first appearance in the
+    dict's iteration order (u before v), as ``dimod.BinaryQuadraticModel.from_qubo`` would add them.
+    If at least half of all pairs carry the same non-zero coefficient it is split off as the
+    uniform pair term ``c_pair`` (the ``2 gamma`` of BQM_clustering.py:46-47), leaving S sparse."""
+    index: Dict[Hashable, int] = {}
+    us, vs, bs = [], [], []
+    for (u, v), b in Q.items():
+        iu = index.setdefault(u, len(index))
+        iv = index.setdefault(v, len(index))
+        us.append(iu)
+        vs.append(iv)
+        bs.append(b)
+    n = len(index)
+    variables = list(index.keys())
+    us = np.asarray(us, dtype=np.int64)
+    vs = np.asarray(vs, dtype=np.int64)
+    bs = np.asarray(bs, dtype=np.float64)
+    lin = np.zeros(n, dtype=np.float64)
+    diag = us == vs
+    np.add.at(lin, us[diag], bs[diag])
+    lo = np.minimum(us[~diag], vs[~diag])
+    hi = np.maximum(us[~diag], vs[~diag])
+    pb = bs[~diag]
+    c_pair = 0.0
+    npairs = n * (n - 1) // 2
+    if detect_uniform and len(pb) and len(pb) * 2 >= npairs and npairs > 0:
+        vals, counts = np.unique(pb, return_counts=True)
+        top = int(np.argmax(counts))
+        # merged (u,v)/(v,u) duplicates would break the "one entry per pair" assumption
+        key = lo * n + hi
+        if counts[top] * 2 >= npairs and vals[top] != 0.0 and len(np.unique(key)) == len(key):
+            c_pair = float(vals[top])
+    if c_pair != 0.0:
+        # pairs absent from the dict have coefficient 0 => sparse part -c_pair there
+        dense_pairs = np.zeros((n, n), dtype=np.float64)
+        dense_pairs[lo, hi] = pb
+        iu, ju = np.triu_indices(n, 1)
+        resid = dense_pairs[iu, ju] - c_pair
+        nz = resid != 0.0
+        rowptr, col, val = _csr_from_edges(n, iu[nz].astype(np.int32), ju[nz].astype(np.int32),
+                                           resid[nz])
+    else:
+        rowptr, col, val = _csr_from_edges(n, lo.astype(np.int32), hi.astype(np.int32), pb)
+    return QuboModel(variables, lin, rowptr, col, val, c_pair=c_pair, offset=float(offset),
+                     info={"kind": "dict"})
+
+
+def add_size_window_penalty(model: QuboModel, lb: float, ub: float, lagrange_multiplier: float,
+                            slack_prefix: str = "slack_c1_constraint_") -> QuboModel:
+    """Penalty form of ``bqm.add_linear_inequality_constraint([(x_i, 1)...], lb, ub, lagrange)``
+    (BQM_clustering.py:373-380): adds binary slack variables ``t_b`` with ``lb + sum_b c_b t_b``
+    spanning ``[lb, floor(ub)]`` and the energy ``lagrange * (sum_i x_i - lb - sum_b c_b t_b)^2``.
+    Returned as a dense-backed QuboModel over ``variables + slack`` (small O(log n) growth)."""
+    n = model.num_variables
+    ub_c = int(np.floor(ub))
+    lb_c = int(np.ceil(lb))
+    span = max(ub_c - lb_c, 0)
+    coeffs: List[int] = []
+    rem = span
+    b = 1
+    while rem > 0:
+        c = min(b, rem)
+        coeffs.append(c)
+        rem -= c
+        b *= 2
+    ns = len(coeffs)
+    a = np.concatenate([np.ones(n), -np.asarray(coeffs, dtype=np.float64)])   # sum a_i z_i - lb
+    N = n + ns
+    Qs = np.zeros((N, N), dtype=np.float64)
+    Qs[:n, :n] = model.dense_Qs()
+    lam = float(lagrange_multiplier)
+    # lam (a.z - lb)^2 = lam [ sum_i a_i^2 z_i + 2 sum_{i<j} a_i a_j z_i z_j - 2 lb a.z + lb^2 ]
+    outer = lam * np.outer(a, a)
+    Qs += outer - np.diag(np.diag(outer))
+    Qs[np.arange(N), np.arange(N)] += lam * (a * a - 2.0 * lb_c * a)
+    variables = list(model.variables) + [slack_prefix + str(i) for i in range(ns)]
+    out = QuboModel(variables, np.diag(Qs).copy(), np.zeros(N + 1, dtype=np.int32),
+                    np.zeros(0, dtype=np.int32), np.zeros(0), c_pair=0.0,
+                    offset=model.offset + lam * lb_c * lb_c,
+                    info=dict(model.info, slack=ns, lb=lb_c, ub=ub_c))
+    out._dense = Qs
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# schedules (neal-compatible defaults with the degenerate-range guard of SURVEY.md 8c)
+# --------------------------------------------------------------------------------------------
+def default_beta_range(model: QuboModel, rel_zero: float = 1e-9) -> Tuple[float, float]:
+    """neal's rule ``beta_hot = ln2 / (2 max_i(|h_i| + sum_j |J_ij|))``, ``beta_cold = ln100 /
+    (2 min nonzero |bias|)`` on the Ising form (h_i = Q_ii/2 + sum_j Q_ij/4, J_ij = Q_ij/4), with
+    biases below ``rel_zero * max|J|`` treated as exactly zero: for A1 the h_i vanish analytically
+    but evaluate to ~1e-14, which would otherwise give beta_cold ~ 5e15."""
+    n = model.num_variables
+    if model._dense is not None:
+        Qs = model._dense
+        off = Qs - np.diag(np.diag(Qs))
+        J_abs_rowsum = np.abs(off).sum(axis=1) / 2.0
+        h = np.diag(Qs) / 2.0 + off.sum(axis=1) / 2.0
+        nzJ = np.abs(off[off != 0.0]) / 2.0
+    else:
+        rows = np.repeat(np.arange(n), np.diff(model.rowptr))
+        pair_sum = np.zeros(n)
+        np.add.at(pair_sum, rows, model.val)
+        pair_sum += model.c_pair * (n - 1)
+        h = model.lin / 2.0 + pair_sum / 4.0
+        full = model.val + model.c_pair
+        abs_sum = np.zeros(n)
+        np.add.at(abs_sum, rows, np.abs(full) - abs(model.c_pair))
+        abs_sum += abs(model.c_pair) * (n - 1)
+        J_abs_rowsum = abs_sum / 4.0
+        cand = [np.abs(full[full != 0.0]) / 4.0]
+        if model.c_pair != 0.0 and len(model.val) < n * (n - 1):
+            cand.append(np.array([abs(model.c_pair) / 4.0]))
+        nzJ = np.concatenate(cand) if cand else np.zeros(0)
+    maxJ = float(nzJ.max()) if len(nzJ) else 0.0
+    scale = max(maxJ, float(np.max(np.abs(h))) if n else 0.0)
+    tiny = rel_zero * scale
+    h_eff = np.where(np.abs(h) > tiny, np.abs(h), 0.0)
+    max_field = float(np.max(h_eff + J_abs_rowsum)) if n else 1.0
+    biases = np.concatenate([h_eff[h_eff > 0.0], nzJ[nzJ > tiny]])
+    min_bias = float(biases.min()) if len(biases) else 1.0
+    if max_field <= 0.0:
+        max_field = 1.0
+    beta_hot = np.log(2.0) / (2.0 * max_field)
+    beta_cold = np.log(100.0) / (2.0 * min_bias)
+    return float(beta_hot), float(beta_cold)
+
+
+def make_beta_schedule(num_sweeps: int, beta_range: Sequence[float],
+                       beta_schedule_type: str = "geometric", num_sweeps_per_beta: int = 1,
+                       beta_schedule: Optional[Sequence[float]] = None) -> np.ndarray:
+    """neal-style schedule expanded to one beta per sweep (float64[num_sweeps])."""
+    if beta_schedule_type == "custom":
+        if beta_schedule is None:
+            raise ValueError("'beta_schedule' must be provided for beta_schedule_type = 'custom'")
+        b = np.asarray(beta_schedule, dtype=np.float64)
+        if np.any(b < 0) or not np.all(np.isfinite(b)):
+            raise ValueError("'beta_schedule' cannot include negative or non-finite values")
+        return np.repeat(b, num_sweeps_per_beta)
+    if num_sweeps_per_beta < 1:
+        raise ValueError("'num_sweeps_per_beta' must be a positive integer")
+    if num_sweeps % num_sweeps_per_beta != 0:
+        raise ValueError("'num_sweeps' must be divisible by 'num_sweeps_per_beta'")
+    num_betas = num_sweeps // num_sweeps_per_beta
+    hot, cold = float(beta_range[0]), float(beta_range[1])
+    if hot < 0 or cold < 0:
+        raise ValueError("beta_range values must be non-negative")
+    if num_betas == 0:
+        return np.zeros(0, dtype=np.float64)
+    if beta_schedule_type == "linear":
+        b = np.linspace(hot, cold, num=num_betas)
+    elif beta_schedule_type == "geometric":
+        if hot <= 0 or cold <= 0:
+            raise ValueError("'beta_range' must contain non-zero values for a geometric schedule")
+        b = np.geomspace(hot, cold, num=num_betas)
+    else:
+        raise ValueError("Beta schedule type {} not implemented".format(beta_schedule_type))
+    return np.repeat(b, num_sweeps_per_beta)

@@ -1,0 +1,212 @@
+"""A ``dimod.SampleSet`` look-alike covering the members the reference reads:
+
+* ``.data(fields=[...])`` iterating in ASCENDING energy   (BQM_clustering.py:93, :281, :397)
+* ``.first.sample`` / ``.first.energy`` / ``.first.num_occurrences``  (BQM_clustering.py:105;
+  DQM_clustering.py:46; main.py:175-177)
+* ``.record.energy`` indexed as if ascending               (BQM_clustering.py:133-143, :321-323)
+* ``.samples()[:k]``                                       (plot_and_save.py:106)
+* ``.first.sample.values()`` in variable order             (plot_and_save.py:38)
+* ``.info['embedding_context']['embedding']``              (BQM_clustering.py:79)
+
+Records are stored sorted ascending by energy and aggregated (identical samples merged, their
+``num_occurrences`` summed) -- what a QPU returns in ``answer_mode="histogram"`` and what the
+reference's "conf" rule silently assumes.  ``to_dimod()`` converts to a real ``dimod.SampleSet``
+when dimod is importable.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from collections.abc import Mapping, Sequence
+from typing import Any, Dict, Hashable, Iterator, List, Optional
+
+import numpy as np
+
+
+class SampleView(Mapping):
+    """Read-only mapping variable label -> value for one record (dimod's SampleView)."""
+
+    __slots__ = ("_row", "_variables", "_index")
+
+    def __init__(self, row, variables, index):
+        self._row = row
+        self._variables = variables
+        self._index = index
+
+    def __getitem__(self, v):
+        return int(self._row[self._index[v]])
+
+    def __iter__(self):
+        return iter(self._variables)
+
+    def __len__(self):
+        return len(self._variables)
+
+    def values(self):
+        return [int(x) for x in self._row]
+
+    def items(self):
+        return list(zip(self._variables, self.values()))
+
+    def __repr__(self):
+        return repr(dict(self.items()))
+
+
+class SamplesArray(Sequence):
+    """``sampleset.samples()``: sequence of SampleViews supporting slicing and 2-d indexing."""
+
+    def __init__(self, rows, variables, index):
+        self._rows = rows
+        self._variables = variables
+        self._index = index
+
+    def __len__(self):
+        return self._rows.shape[0]
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):                       # samples[r, v]
+            r, v = key
+            if isinstance(v, (list, np.ndarray)):
+                cols = [self._index[x] for x in v]
+                return self._rows[r][..., cols]
+            return self._rows[r][..., self._index[v]]
+        if isinstance(key, slice):
+            return SamplesArray(self._rows[key], self._variables, self._index)
+        return SampleView(self._rows[key], self._variables, self._index)
+
+    def __iter__(self):
+        for r in range(len(self)):
+            yield SampleView(self._rows[r], self._variables, self._index)
+
+
+class SampleSet:
+    def __init__(self, samples: np.ndarray, energies: np.ndarray, variables: List[Hashable],
+                 vartype: str = "BINARY", num_occurrences: Optional[np.ndarray] = None,
+                 info: Optional[Dict[str, Any]] = None, aggregate: bool = True,
+                 sort: bool = True, extra: Optional[Dict[str, np.ndarray]] = None):
+        samples = np.asarray(samples)
+        if samples.ndim == 1:
+            samples = samples[None, :]
+        energies = np.asarray(energies, dtype=np.float64).reshape(-1)
+        if samples.shape[0] != energies.shape[0]:
+            raise ValueError("samples and energies disagree on the number of rows")
+        if samples.shape[1] != len(variables):
+            raise ValueError("samples and variables disagree on the number of columns")
+        occ = (np.ones(len(energies), dtype=np.int64) if num_occurrences is None
+               else np.asarray(num_occurrences, dtype=np.int64))
+        extra = dict(extra or {})
+        if aggregate and len(energies) > 1:
+            uniq, first, inverse = np.unique(samples, axis=0, return_index=True,
+                                             return_inverse=True)
+            inverse = np.asarray(inverse).reshape(-1)
+            occ = np.bincount(inverse, weights=occ, minlength=len(first)).astype(np.int64)
+            samples, energies = uniq, energies[first]
+            extra = {k: np.asarray(v)[first] for k, v in extra.items()}
+        if sort and len(energies) > 1:
+            order = np.argsort(energies, kind="stable")
+            samples, energies, occ = samples[order], energies[order], occ[order]
+            extra = {k: np.asarray(v)[order] for k, v in extra.items()}
+        dt = np.int8 if vartype in ("BINARY", "SPIN") else np.int32
+        self._samples = np.ascontiguousarray(samples, dtype=dt)
+        self.variables = list(variables)
+        self._index = {v: i for i, v in enumerate(self.variables)}
+        self.vartype = vartype
+        self.info = dict(info or {})
+        fields = [("sample", dt, (len(self.variables),)), ("energy", np.float64),
+                  ("num_occurrences", np.int64)]
+        for k, v in extra.items():
+            fields.append((k, np.asarray(v).dtype))
+        rec = np.recarray(len(energies), dtype=fields)
+        rec["sample"] = self._samples
+        rec["energy"] = energies
+        rec["num_occurrences"] = occ
+        for k, v in extra.items():
+            rec[k] = v
+        self.record = rec
+
+    # -- dimod-compatible accessors ---------------------------------------------------------------
+    def __len__(self):
+        return len(self.record)
+
+    def __iter__(self):
+        return iter(self.samples())
+
+    def samples(self, n: Optional[int] = None, sorted_by: Optional[str] = "energy") -> SamplesArray:
+        rows = self.record["sample"]
+        if sorted_by is not None and len(self.record) > 1:
+            rows = rows[np.argsort(self.record[sorted_by], kind="stable")]
+        if n is not None:
+            rows = rows[:n]
+        return SamplesArray(rows, self.variables, self._index)
+
+    def data(self, fields=None, sorted_by: Optional[str] = "energy", name: str = "Sample",
+             reverse: bool = False, sample_dict_cast: bool = True, index: bool = False) -> Iterator:
+        rec = self.record
+        if fields is None:
+            fields = [f for f in rec.dtype.names]
+        order = np.arange(len(rec))
+        if sorted_by is not None and len(rec) > 1:
+            order = np.argsort(rec[sorted_by], kind="stable")
+        if reverse:
+            order = order[::-1]
+        names = list(fields) + (["idx"] if index else [])
+        tup = namedtuple(name, names) if name else None
+        for i in order:
+            vals = []
+            for f in fields:
+                if f == "sample":
+                    view = SampleView(rec["sample"][i], self.variables, self._index)
+                    vals.append(dict(view.items()) if sample_dict_cast else view)
+                else:
+                    v = rec[f][i]
+                    vals.append(v.item() if hasattr(v, "item") else v)
+            if index:
+                vals.append(int(i))
+            yield tup(*vals) if tup else tuple(vals)
+
+    @property
+    def first(self):
+        if len(self.record) == 0:
+            raise ValueError("{} is empty".format(self.__class__.__name__))
+        return next(self.data(sorted_by="energy", name="Sample", sample_dict_cast=False))
+
+    def lowest(self, rtol: float = 1e-5, atol: float = 1e-8) -> "SampleSet":
+        e = self.record["energy"]
+        keep = np.isclose(e, e.min(), rtol=rtol, atol=atol)
+        return SampleSet(self.record["sample"][keep], e[keep], self.variables, self.vartype,
+                         self.record["num_occurrences"][keep], self.info, aggregate=False)
+
+    def aggregate(self) -> "SampleSet":
+        return SampleSet(self.record["sample"], self.record["energy"], self.variables, self.vartype,
+                         self.record["num_occurrences"], self.info, aggregate=True)
+
+    def change_vartype(self, vartype: str, energy_offset: float = 0.0) -> "SampleSet":
+        s = self.record["sample"]
+        if vartype == self.vartype:
+            out = s
+        elif vartype == "SPIN" and self.vartype == "BINARY":
+            out = 2 * s.astype(np.int8) - 1
+        elif vartype == "BINARY" and self.vartype == "SPIN":
+            out = (s.astype(np.int8) + 1) // 2
+        else:
+            raise ValueError("cannot convert %s to %s" % (self.vartype, vartype))
+        return SampleSet(out, self.record["energy"] + energy_offset, self.variables, vartype,
+                         self.record["num_occurrences"], self.info, aggregate=False, sort=False)
+
+    def to_dimod(self):
+        """Real ``dimod.SampleSet`` (requires dimod; not available in the build container)."""
+        import dimod  # noqa: WPS433  (optional dependency)
+        vt = {"BINARY": dimod.BINARY, "SPIN": dimod.SPIN}.get(self.vartype, "DISCRETE")
+        return dimod.SampleSet.from_samples((self.record["sample"], self.variables),
+                                            energy=self.record["energy"],
+                                            num_occurrences=self.record["num_occurrences"],
+                                            vartype=vt, info=self.info, sort_labels=False)
+
+    def __repr__(self):
+        head = ["SampleSet(%d rows, %d variables, %s)" % (len(self), len(self.variables),
+                                                          self.vartype)]
+        for k, row in enumerate(self.data(fields=["energy", "num_occurrences"])):
+            if k >= 5:
+                head.append("  ...")
+                break
+            head.append("  energy=%.9g  num_occ=%d" % (row.energy, row.num_occurrences))
+        return "\n".join(head)
