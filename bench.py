@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- spin-flip updates/s of the dense-QUBO anneal on the PBMC3k-sized SNN model.
+
+Workload (BASELINE.json configs[1]): synthetic PBMC3k-like SNN graph, n = 2638 cells (k=5, dim=15,
+trim 15; no PBMC data ships with the reference), `clustering_bqm` model (BQM_clustering.py:29-47,
+gamma_factor 0.05, k 8) as a dense fp32 Q (27.8 MB) resident in HBM; ONE STEP = one anneal of
+4096 replicas x 1000 sweeps per GPU (explicit geometric beta schedule, seed 1234).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Multi-GPU: replicas shard (weak scaling: 4096 replicas per GPU, global ids rank*4096..), the model is
+replicated, and each step ends with the ONE exchange the path has: a 64-bit MIN all-reduce of the
+packed (energy, replica id) key + a broadcast of the winner's labels (RCCL over xGMI).
+
+Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes (4n per proposal, SURVEY.md
+section 8d) / HIP-event kernel time; it exceeds HBM peak when rows are served from L2 / Infinity Cache
+and because cached local fields need a row only for ACCEPTED moves -- `rows_GBps` gives the bytes the
+kernel really requested.  `cpu_baseline` times the oracle's neal restatement on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_CELLS, K_NN, DIM, ORD, N_CLUSTERS = 2638, 5, 15, 15, 9
+REPLICAS_PER_GPU, SWEEPS, SEED = 4096, 1000, 1234
+HBM_PEAK_GBPS = 8000.0
+
+
+def build_workload():
+    from scrna_seq_qannealing_clustering_amd import graphs, models
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(N_CELLS, K_NN, DIM, ORD, N_CLUSTERS, seed=0)
+    G = graphs.EdgeListGraph(nodes, eu, ev, w)
+    m = models.build_bqm_qubo(G, 0.05, k=8)
+    Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))
+    betas = models.make_beta_schedule(SWEEPS, models.default_beta_range(m))
+    return m, Qs, betas, (eu, ev, w)
+
+
+def cpu_baseline(Qs, betas, seconds_target=15.0):
+    """The oracle's restatement of dwave-neal (Ising, fp64, xorshift128+, sequential sweeps) on a bounded
+    sample of the SAME workload: same Q, every (len/sweeps)-th beta of the same schedule."""
+    from oracle import sa_oracle as so
+    h, J, off = so.qubo_to_ising_dense(Qs.astype(np.float64))
+    # the GPU box shares its host: one GPU's share is 16 cores (more threads only oversubscribe)
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), int(os.environ.get("MI_CPU_THREADS", "16")))
+    sweeps = 50
+    sub = betas[:: max(1, len(betas) // sweeps)][:sweeps]
+    # calibrate on 1 read, 1 thread ("how neal runs": reads are sequential, single-threaded)
+    t0 = time.perf_counter()
+    _, e1, st1 = so.sa_ising_neal_dense(h, J, 1, sub, seed=SEED, threads=1)
+    t1 = time.perf_counter() - t0
+    single = float(st1[0]) / t1
+    reads = int(max(cores, min(64 * cores, (seconds_target / max(t1, 1e-3)) * cores)))
+    t0 = time.perf_counter()
+    _, en, st = so.sa_ising_neal_dense(h, J, reads, sub, seed=SEED, threads=cores)
+    t = time.perf_counter() - t0
+    return {
+        "value": float(st[0]) / t, "unit": "spin-flip updates/s", "cores": cores, "kind": "port",
+        "single_thread_value": single,
+        "best_energy": float((en + off).min()),
+        "sample": "oracle neal restatement (fp64 Ising, xorshift128+), same dense Q, %d reads x %d sweeps "
+                  "(every %d-th beta of the 1000-sweep schedule), OpenMP over reads on %d threads; "
+                  "real dwave-neal is not installable offline" % (reads, len(sub), max(1, len(betas) // sweeps), cores),
+        "seconds": t,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
+    ap.add_argument("--sweeps", type=int, default=SWEEPS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from scrna_seq_qannealing_clustering_amd import distributed as D
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local)
+
+    m, Qs, betas, (eu, ev, w) = build_workload()
+    if args.sweeps != SWEEPS:
+        from scrna_seq_qannealing_clustering_amd import models
+        betas = models.make_beta_schedule(args.sweeps, models.default_beta_range(m))
+    R = args.replicas
+    n = Qs.shape[0]
+    prob = Problem.dense(Qs, offset=0.0, device=local)             # Q resident in HBM before timing
+
+    def step(i):
+        prob.anneal(R, betas, SEED + i, replica_offset=rank * R)
+        idx, e, key, state = prob.best()                           # K5 on device; waits for the anneal
+        return D.global_best(key, state)                           # C1 + C2 (identity at N=1)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    best = None
+    for i in range(args.steps):
+        best = step(args.warmup + i)
+        kernel_ms.append(prob.kernel_ms())                         # HIP events on the engine's stream
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    _, en, info = prob.fetch()
+    updates_per_step = world * R * len(betas) * n
+    value = updates_per_step * args.steps / elapsed
+    k_ms = float(np.mean(kernel_ms))
+    alg_bytes = 4.0 * n * R * len(betas) * n                       # per launch (one GPU)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    row_bytes = info["accepted"] * (((n + 255) // 256) * 256 * 4)  # padded row actually requested
+    best_state = best[3]
+    cut_edges = int(np.sum(best_state[eu] != best_state[ev]))
+    out = {
+        "metric": "spin-flip updates/sec (node) + best QUBO energy vs neal, PBMC3k SNN",
+        "value": value, "unit": "spin-flip updates/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PBMC3k-sized synthetic SNN (n=2638, k=5, dim=15, trim 15), clustering_bqm QUBO "
+                               "(gamma_factor 0.05, k 8), dense fp32 Q 27.8 MB in HBM, %d replicas/GPU x %d sweeps, "
+                               "geometric beta, seed 1234" % (R, len(betas)),
+                   "n": n, "replicas_per_gpu": R, "sweeps": int(len(betas)), "parallelism": "replicas sharded x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "k_anneal_dense<44>", "kernel_ms": k_ms,
+                     "algorithmic_bytes_per_update": 4 * n,
+                     "rows_GBps": row_bytes / (k_ms * 1e-3) / 1e9,
+                     "acceptance": info["accepted"] / info["proposals"]},
+        "best_energy": float(m.energies(best_state[None, :])[0]),
+        "best_energy_device_f32": float(best[0]),
+        "best_cut_edges": cut_edges,
+        "energy_lower_bound": float(-m.info["gamma"] * n * n / 4),
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(Qs, betas)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    prob.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -389,7 +389,7 @@ int ensure_run_buffers(mi_sa_problem *p, int R, int num_sweeps, bool need_init)
         p->cap_R = R;
     }
     if (need_init && !p->d_init) HIP_TRY(hipMalloc(&p->d_init, (size_t)p->cap_R * p->n * p->state_elem));
-    if (num_sweeps > p->cap_sweeps) {
+    if (num_sweeps > p->cap_sweeps || !p->d_temps) {
         if (p->d_temps) (void)hipFree(p->d_temps);
         p->d_temps = nullptr;
         HIP_TRY(hipMalloc((void **)&p->d_temps, (size_t)(num_sweeps > 0 ? num_sweeps : 1) * sizeof(float)));

@@ -1,0 +1,200 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI (libmi_sa.so).  GPU only.
+
+Bars: binary states / accepted-move counts / integer edge cuts are BIT-EXACT; device energies are
+fp64 sums of fp32 fields, compared at rel 1e-5 (the chain computes in fp32)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import GRAPH_NAMES, load_fixture
+from oracle import sa_oracle as so
+from scrna_seq_qannealing_clustering_amd import _lib, engine, models
+from scrna_seq_qannealing_clustering_amd.engine import Problem
+
+pytestmark = pytest.mark.gpu
+
+E_RTOL = 1e-5
+
+
+def fixture_model(name, gf=0.05):
+    fx = load_fixture(name)
+    m = models.build_bqm_qubo(fx.graph(), gf)
+    return fx, m, np.ascontiguousarray(m.dense_Qs().astype(np.float32))
+
+
+def random_sym(n, seed, scale=1.0):
+    rng = np.random.RandomState(seed)
+    A = rng.normal(scale=scale, size=(n, n)).astype(np.float32)
+    Q = ((A + A.T) * np.float32(0.5)).astype(np.float32)
+    return np.ascontiguousarray((Q + Q.T) * np.float32(0.5))
+
+
+def run_gpu(Qs, R, betas, seed, **kw):
+    with Problem.dense(Qs, offset=kw.pop("offset", 0.0)) as p:
+        p.anneal(R, betas, seed, **kw)
+        st, en, info = p.fetch()
+    return st, en, info
+
+
+@pytest.mark.parametrize("name", GRAPH_NAMES)
+def test_trajectory_parity_on_reference_graphs(name):
+    fx, m, Qs = fixture_model(name)
+    betas = models.make_beta_schedule(60, models.default_beta_range(m))
+    st, en, info = run_gpu(Qs, 16, betas, 1234)
+    ost, oen, ostats = so.sa_dense_philox(Qs, 16, betas, 1234)
+    assert np.array_equal(st, ost)                                   # flip for flip
+    assert info["accepted"] == int(ostats[1]) and info["proposals"] == int(ostats[0])
+    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-3)
+    assert np.array_equal(so.cut_edges(fx.eu, fx.ev, st), so.cut_edges(fx.eu, fx.ev, ost))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 300, 777, 1000])
+def test_trajectory_parity_ragged_sizes(n):
+    Qs = random_sym(n, seed=n)
+    betas = np.geomspace(0.05, 5.0, 12)
+    st, en, info = run_gpu(Qs, 5, betas, 42 + n, offset=1.25)
+    ost, oen, ostats = so.sa_dense_philox(Qs, 5, betas, 42 + n, offset=1.25)
+    assert np.array_equal(st, ost)
+    assert info["accepted"] == int(ostats[1])
+    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-3)
+
+
+def test_initial_states_resync_and_zero_sweeps():
+    fx, m, Qs = fixture_model("noisy_moons")
+    rng = np.random.RandomState(9)
+    init = rng.randint(0, 2, size=(6, 256)).astype(np.uint8)
+    betas = models.make_beta_schedule(40, models.default_beta_range(m))
+    for resync in (0, 1, 7):
+        st, en, info = run_gpu(Qs, 6, betas, 5, initial_states=init, resync_interval=resync)
+        ost, oen, ostats = so.sa_dense_philox(Qs, 6, betas, 5, init=init, resync_interval=resync)
+        assert np.array_equal(st, ost) and info["accepted"] == int(ostats[1])
+    # zero sweeps: the initial states come back, with their energies
+    st, en, _ = run_gpu(Qs, 6, betas[:0], 5, initial_states=init)
+    assert np.array_equal(st, init)
+    assert np.allclose(en, so.energy_dense_f64(Qs, init), rtol=E_RTOL)
+    # zero sweeps without initial states: the replica's own random initial state
+    st, en, _ = run_gpu(Qs, 6, betas[:0], 5)
+    ost, _, _ = so.sa_dense_philox(Qs, 6, betas[:0], 5)
+    assert np.array_equal(st, ost) and 0.3 < st.mean() < 0.7
+
+
+def test_replica_sharding_is_invariant():
+    """Global replica ids key the RNG: [0,8) in one run == [0,4) + [4,8) in two (multi-GPU rule)."""
+    _, m, Qs = fixture_model("varied")
+    betas = models.make_beta_schedule(30, models.default_beta_range(m))
+    st, en, _ = run_gpu(Qs, 8, betas, 77)
+    a, ea, _ = run_gpu(Qs, 4, betas, 77, replica_offset=0)
+    b, eb, _ = run_gpu(Qs, 4, betas, 77, replica_offset=4)
+    assert np.array_equal(st, np.concatenate([a, b])) and np.array_equal(en, np.concatenate([ea, eb]))
+    ob, _, _ = so.sa_dense_philox(Qs, 4, betas, 77, replica_offset=4)
+    assert np.array_equal(b, ob)
+
+
+def test_circles_reaches_proven_optimum(kat):
+    """P3 on the reference's own graph: best of 64 x 1000 sweeps == known global optimum, cut = 0,
+    and equal to the oracle's best at the same (R, sweeps, schedule, seed)."""
+    fx, m, Qs = fixture_model("noisy_circles")
+    betas = models.make_beta_schedule(1000, models.default_beta_range(m))
+    with Problem.dense(Qs) as p:
+        p.anneal(64, betas, 1234)
+        st, en, info = p.fetch()
+        idx, e_best, key, s_best = p.best()
+    ost, oen, _ = so.sa_dense_philox(Qs, 64, betas, 1234)
+    assert np.array_equal(st, ost)
+    assert idx == int(np.argmin(en.astype(np.float32))) or en[idx] == en.min()
+    assert e_best == pytest.approx(kat["noisy_circles"]["comp0_E_closed"], rel=1e-6)
+    assert int(so.cut_edges(fx.eu, fx.ev, s_best[None, :])[0]) == 0 and int(s_best.sum()) == 128
+    assert m.energies(s_best[None, :])[0] == pytest.approx(-2951.8108596597776, rel=1e-12)
+    assert en.min() <= oen.min() + 1e-3
+    from scrna_seq_qannealing_clustering_amd.distributed import unpack_key
+    e32, gid = unpack_key(key)
+    assert gid == idx and e32 == pytest.approx(e_best, rel=1e-6)
+
+
+def test_energy_kernel_parity():
+    fx, m, Qs = fixture_model("aniso")
+    rng = np.random.RandomState(3)
+    X = rng.randint(0, 2, size=(37, 256)).astype(np.uint8)
+    X[0] = 0
+    X[1] = 1
+    got = engine.energy_dense(Qs, X, offset=-2.0)
+    want = so.energy_dense_f64(Qs, X, offset=-2.0)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-4)
+    assert got[0] == -2.0
+    # Z2 symmetry of the balanced-partition model: E(x) == E(1 - x)
+    assert np.allclose(engine.energy_dense(Qs, 1 - X), engine.energy_dense(Qs, X), rtol=1e-6, atol=2e-3)
+    Qr = random_sym(130, 8)
+    Xr = rng.randint(0, 2, size=(3, 130)).astype(np.uint8)
+    assert np.allclose(engine.energy_dense(Qr, Xr), so.energy_dense_f64(Qr, Xr), rtol=1e-6, atol=1e-4)
+
+
+def test_one_shot_c_entry_point():
+    _, m, Qs = fixture_model("blobs")
+    betas = np.ascontiguousarray(models.make_beta_schedule(25, models.default_beta_range(m)))
+    lib = _lib.load()
+    R, n = 7, 256
+    st = np.zeros((R, n), dtype=np.uint8)
+    en = np.zeros(R)
+    stats = np.zeros(3, dtype=np.uint64)
+    rc = lib.mi_sa_qubo_dense_f32(
+        Qs.ctypes.data_as(C.POINTER(C.c_float)), n, 0.0, R, len(betas),
+        betas.ctypes.data_as(C.POINTER(C.c_double)), 31337, None,
+        st.ctypes.data_as(C.POINTER(C.c_uint8)), en.ctypes.data_as(C.POINTER(C.c_double)),
+        stats.ctypes.data_as(C.POINTER(C.c_uint64)), 0)
+    assert rc == 0, lib.mi_last_error()
+    ost, oen, ostats = so.sa_dense_philox(Qs, R, betas, 31337)
+    assert np.array_equal(st, ost) and int(stats[0]) == R * 25 * n and int(stats[1]) == int(ostats[1])
+
+
+def test_error_behaviour():
+    lib = _lib.load()
+    with pytest.raises(ValueError):
+        Problem.dense(np.array([[0.0, 1.0], [2.0, 0.0]], dtype=np.float32))       # not symmetric
+    with pytest.raises(_lib.MiSaError) as ei:
+        Problem.dense(np.zeros((4097, 4097), dtype=np.float32))
+    assert ei.value.code == -5
+    with pytest.raises(_lib.MiSaError):
+        Problem.dense(np.zeros((4, 4), dtype=np.float32), device=99)
+    p = Problem.dense(np.zeros((4, 4), dtype=np.float32))
+    with pytest.raises(RuntimeError):
+        p.fetch()
+    with pytest.raises(_lib.MiSaError):
+        p.anneal(0, [1.0], 1)
+    with pytest.raises(_lib.MiSaError):
+        p.anneal(2, [1.0, -1.0], 1)
+    with pytest.raises(_lib.MiSaError):
+        p.anneal(2, [1.0, float("nan")], 1)
+    with pytest.raises(ValueError):
+        p.anneal(2, [1.0], 1, initial_states=np.zeros((3, 4)))
+    p.close()
+    assert b"" == b"" and lib.mi_last_error() is not None
+
+
+def test_full_size_properties_pbmc3k_surrogate():
+    """BASELINE config 2 shape (n = 2638): size-independent properties + a 2-replica bit-exact spot check."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(2638, 5, 15, 15, 9, seed=0)
+    m = models.build_bqm_qubo(graphs.EdgeListGraph(nodes, eu, ev, w), 0.05)
+    Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))
+    betas = models.make_beta_schedule(20, models.default_beta_range(m))
+    with Problem.dense(Qs) as p:
+        p.anneal(256, betas, 1234)
+        st, en, info = p.fetch()
+        p.anneal(256, betas, 1234)
+        st2, en2, _ = p.fetch()
+        p.anneal(2, betas[:8], 5, replica_offset=100)
+        s2, e2, i2 = p.fetch()
+    assert np.array_equal(st, st2) and np.array_equal(en, en2)                 # deterministic
+    assert set(np.unique(st).tolist()) <= {0, 1}
+    host = m.energies(st)                                                      # fp64, structured form
+    assert np.allclose(en, host, rtol=E_RTOL)
+    cut = so.cut_edges(eu, ev, st)
+    s = st.sum(axis=1).astype(np.float64)
+    cut_w = np.array([w[(x[eu] != x[ev])].sum() for x in st])
+    closed = 8 * cut_w + m.info["gamma"] * (s * s - 2638 * s)                   # E = k cut + gamma (s^2 - n s)
+    assert np.allclose(host, closed, rtol=1e-9)
+    assert cut.min() >= 0 and info["proposals"] == 256 * 20 * 2638
+    assert 0.05 < info["accepted"] / info["proposals"] < 0.7
+    o2, oe2, os2 = so.sa_dense_philox(Qs, 2, betas[:8], 5, replica_offset=100)
+    assert np.array_equal(s2, o2) and i2["accepted"] == int(os2[1])

@@ -1,0 +1,70 @@
+"""The dimod-style surface on the GPU: what `clustering_bqm` / `clustering_dqm` see.  GPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture
+from oracle import model_oracle as mo
+from scrna_seq_qannealing_clustering_amd import MI355XSampler, models
+from scrna_seq_qannealing_clustering_amd.bqm import BinaryQuadraticModel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sample_qubo_with_reference_dict_and_qpu_kwargs():
+    fx = load_fixture("noisy_circles")
+    Q, gamma = mo.q_bqm(fx.nodes, fx.edges, 0.05, edges_weights=fx.W)      # the reference's own dict
+    sampler = MI355XSampler()
+    resp = sampler.sample_qubo(Q, label="256_graph_snn_fixed_embedding", chain_strength=20,
+                               num_reads=64, return_embedding=True, num_sweeps=1000, seed=1234)
+    # what BQM_clustering.py:93-109 does with the response
+    rows = list(resp.data(fields=["sample", "energy", "num_occurrences"]))
+    assert all(rows[i].energy <= rows[i + 1].energy for i in range(len(rows) - 1))
+    lut = resp.first.sample
+    S0 = [node for node in fx.nodes if not lut[node]]
+    S1 = [node for node in fx.nodes if lut[node]]
+    assert len(S0) == 128 and len(S1) == 128
+    assert resp.first.energy == pytest.approx(-2951.8108596597776, rel=1e-9)   # fp64 host re-evaluation
+    assert mo.cut_edges(fx.edges, dict(lut)) == 0
+    assert resp.record.energy[0] == resp.first.energy and len(resp.record.energy) > 3
+    assert resp.info["embedding_context"]["embedding"] == {}
+    assert set(resp.info["ignored_kwargs"]) == {"label", "chain_strength", "return_embedding"}
+    assert sum(resp.record.num_occurrences) == 64
+    assert resp.info["device_energy_max_abs_diff"] < 0.05
+    with pytest.raises(TypeError):
+        sampler.sample_qubo(Q, bogus_argument=1)
+
+
+def test_sample_bqm_spin_and_binary_agree():
+    rng = np.random.RandomState(0)
+    n = 40
+    h = {i: float(rng.normal()) for i in range(n)}
+    J = {(i, j): float(rng.normal()) for i in range(n) for j in range(i + 1, n) if rng.rand() < 0.3}
+    sampler = MI355XSampler()
+    ss = sampler.sample_ising(h, J, num_reads=32, num_sweeps=300, seed=3)
+    assert ss.vartype == "SPIN" and set(np.unique(ss.record.sample).tolist()) <= {-1, 1}
+    bqm = BinaryQuadraticModel.from_ising(h, J)
+    for row in list(ss.data(fields=["sample", "energy"]))[:5]:
+        assert row.energy == pytest.approx(bqm.energy(row.sample), rel=1e-9, abs=1e-9)
+    # exact optimum of a small instance
+    small = BinaryQuadraticModel.from_ising({i: h[i] for i in range(12)},
+                                            {k: v for k, v in J.items() if k[0] < 12 and k[1] < 12})
+    best = min(small.energy({i: 2 * ((k >> i) & 1) - 1 for i in range(12)}) for k in range(2 ** 12))
+    got = sampler.sample(small, num_reads=32, num_sweeps=200, seed=1)
+    assert got.first.energy == pytest.approx(best, abs=1e-9)
+
+
+def test_initial_states_generators():
+    fx = load_fixture("blobs")
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    sampler = MI355XSampler()
+    init = np.zeros((2, 256), dtype=np.int8)
+    init[1] = 1
+    ss = sampler.sample_qubo(m, initial_states=(init, fx.nodes), num_sweeps=0, initial_states_generator="none")
+    assert len(ss) == 2 and ss.info["num_reads"] == 2
+    ss = sampler.sample_qubo(m, initial_states=(init, fx.nodes), num_reads=6, num_sweeps=0,
+                             initial_states_generator="tile", seed=1)
+    assert sorted(ss.record.num_occurrences.tolist()) == [3, 3]
+    ss = sampler.sample_qubo(m, initial_states=(init, fx.nodes), num_reads=6, num_sweeps=0, seed=1)
+    assert len(ss) == 6                                            # 2 given + 4 random, all distinct
+    with pytest.raises(ValueError):
+        sampler.sample_qubo(m, initial_states=(init, fx.nodes), num_reads=6, initial_states_generator="none")

@@ -1,0 +1,194 @@
+"""Host-side model layer (array-form builders) against the literal restatement of the reference's
+builders in oracle/model_oracle.py.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import GRAPH_NAMES, load_fixture
+from oracle import model_oracle as mo
+from scrna_seq_qannealing_clustering_amd import models
+from scrna_seq_qannealing_clustering_amd.bqm import BinaryQuadraticModel, DiscreteQuadraticModel
+from scrna_seq_qannealing_clustering_amd.sampler import dqm_to_potts
+
+
+def dense_from_dict(Q, variables):
+    idx = {v: i for i, v in enumerate(variables)}
+    n = len(variables)
+    Qs = np.zeros((n, n))
+    for (u, v), b in Q.items():
+        i, j = idx[u], idx[v]
+        if i == j:
+            Qs[i, i] += b
+        else:
+            Qs[i, j] += b / 2
+            Qs[j, i] += b / 2
+    return Qs
+
+
+@pytest.mark.parametrize("name", GRAPH_NAMES)
+def test_build_bqm_matches_reference_dict(name):
+    fx = load_fixture(name)
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    Q, gamma = mo.q_bqm(fx.nodes, fx.edges, 0.05, edges_weights=fx.W)
+    assert m.info["gamma"] == gamma and m.info["W"] == fx.W
+    assert m.variables == fx.nodes
+    ref = dense_from_dict(Q, fx.nodes)
+    got = m.dense_Qs()
+    assert np.array_equal(got, got.T)
+    assert np.allclose(got, ref, rtol=1e-13, atol=1e-13)
+    # energies through the structured (CSR + uniform pair) form == dict sum
+    rng = np.random.RandomState(0)
+    X = rng.randint(0, 2, size=(5, 256))
+    want = [mo.qubo_energy(Q, dict(zip(fx.nodes, x.tolist()))) for x in X]
+    assert np.allclose(m.energies(X), want, rtol=1e-10, atol=1e-8)
+
+
+def test_build_bqm2_bqm3_match_reference_dict():
+    fx = load_fixture("varied")
+    G = fx.graph()
+    m2 = models.build_bqm2_qubo(G, 0.01, 1)
+    Q2, gamma, chain = mo.q_bqm_2(fx.nodes, fx.edges, 0.01, 1, weights_sum=fx.W)
+    assert m2.info["gamma"] == gamma
+    assert m2.info["chain_strength"] == pytest.approx(chain, rel=1e-13)
+    assert np.allclose(m2.dense_Qs(), dense_from_dict(Q2, fx.nodes), rtol=1e-13, atol=1e-13)
+    m3 = models.build_bqm3_cut_qubo(G)
+    assert np.allclose(m3.dense_Qs(), dense_from_dict(mo.q_bqm_3_cut_only(fx.nodes, fx.edges), fx.nodes),
+                       rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["noisy_circles", "blobs"])
+def test_build_dqm_matches_reference_overwrite_semantics(name):
+    fx = load_fixture(name)
+    K, gamma = 3, 0.005
+    pm = models.build_dqm_potts(fx.graph(), K, gamma)
+    lin, quad = mo.dqm_model(fx.nodes, fx.edges, K, gamma)
+    assert np.array_equal(pm.lin, np.array([lin[v][0] for v in fx.nodes]))   # last-edge-wins
+    rng = np.random.RandomState(1)
+    L = rng.randint(0, K, size=(4, 256))
+    want = [mo.dqm_energy(lin, quad, dict(zip(fx.nodes, l.tolist()))) for l in L]
+    assert np.allclose(pm.energies(L), want, rtol=1e-10)
+
+
+def test_dqm_lookalike_reduces_to_potts():
+    fx = load_fixture("noisy_moons")
+    keep = fx.nodes[:24]
+    ks = set(keep)
+    edges = [(u, v, w) for u, v, w in fx.edges if u in ks and v in ks]
+    K, gamma = 4, 0.3
+    # build exactly as DQM_clustering.py:29-43 does, against the look-alike class
+    from itertools import combinations
+    dqm = DiscreteQuadraticModel()
+    for node in keep:
+        dqm.add_variable(K, label=node)
+    for node in keep:
+        dqm.set_linear(node, [gamma * (1 - len(keep) / K) for _ in range(K)])
+    for i, j in combinations(keep, 2):
+        dqm.set_quadratic(i, j, {(c, c): 2 * gamma for c in range(K)})
+    for u, v, w in edges:
+        dqm.set_quadratic(u, v, {(c, c): -2 * w for c in range(K)})
+        dqm.set_linear(u, [w for _ in range(K)])
+        dqm.set_linear(v, [w for _ in range(K)])
+    pm = dqm_to_potts(dqm)
+    assert pm.c_pair == 2 * gamma and pm.num_cases == K
+    lin, quad = mo.dqm_model(keep, edges, K, gamma)
+    rng = np.random.RandomState(2)
+    for _ in range(5):
+        lab = dict(zip(keep, rng.randint(0, K, size=len(keep)).tolist()))
+        e_ref = mo.dqm_energy(lin, quad, lab)
+        assert dqm.energy(lab) == pytest.approx(e_ref, rel=1e-12)
+        assert pm.energies(np.array([[lab[v] for v in keep]]))[0] == pytest.approx(e_ref, rel=1e-10)
+    # a model that is not in Potts form is refused, not silently mangled
+    dqm.set_quadratic(keep[0], keep[1], {(0, 1): 1.0})
+    with pytest.raises(NotImplementedError):
+        dqm_to_potts(dqm)
+
+
+def test_qubo_dict_roundtrip_and_uniform_detection():
+    fx = load_fixture("aniso")
+    Q, gamma = mo.q_bqm(fx.nodes, fx.edges, 0.05, edges_weights=fx.W)
+    m = models.qubo_dict_to_model(Q)
+    assert m.c_pair == 2 * gamma                           # the 2*gamma pair term is split off
+    assert len(m.val) == 2 * len(fx.edges)                 # sparse part = edges only
+    # variable order = first appearance (u of the first edge, then v, ...)
+    assert m.variables[0] == fx.edges[0][0]
+    assert np.allclose(m.dense_Qs(), dense_from_dict(Q, m.variables), rtol=1e-12, atol=1e-12)
+    # sparse Q (QA_subsampling.py:28-35 shape): no uniform term
+    Qs = {}
+    for u, v, w in fx.edges[:50]:
+        Qs[(u, u)] = Qs.get((u, u), 0) - (1 - w)
+        Qs[(v, v)] = Qs.get((v, v), 0) - (1 - w)
+        Qs[(u, v)] = Qs.get((u, v), 0) + (1 - w)
+    ms = models.qubo_dict_to_model(Qs)
+    assert ms.c_pair == 0.0
+    x = {v: 1 for v in ms.variables}
+    assert ms.energies(np.ones((1, ms.num_variables)))[0] == pytest.approx(mo.qubo_energy(Qs, x), rel=1e-12)
+    # both orientations of a pair are merged
+    m2 = models.qubo_dict_to_model({("a", "b"): 1.0, ("b", "a"): 2.0, ("a", "a"): -1.0})
+    assert m2.energies(np.array([[1, 1]]))[0] == pytest.approx(2.0)
+
+
+def test_default_beta_range_guard_and_schedule():
+    fx = load_fixture("noisy_circles")
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    hot, cold = models.default_beta_range(m)
+    gamma = m.info["gamma"]
+    assert cold == pytest.approx(np.log(100) / (2 * (gamma / 2)), rel=1e-9)    # min |J| = gamma/2
+    # dense-backed copy gives the same range
+    md = models.qubo_dict_to_model(m.to_qubo_dict(), detect_uniform=False)
+    h2, c2 = models.default_beta_range(md)
+    assert h2 == pytest.approx(hot, rel=1e-9) and c2 == pytest.approx(cold, rel=1e-9)
+    b = models.make_beta_schedule(10, (0.1, 10.0))
+    assert b[0] == pytest.approx(0.1) and b[-1] == pytest.approx(10.0) and len(b) == 10
+    assert np.allclose(b[1:] / b[:-1], (10.0 / 0.1) ** (1 / 9))
+    b2 = models.make_beta_schedule(12, (0.1, 1.0), "linear", num_sweeps_per_beta=3)
+    assert len(b2) == 12 and len(set(b2.tolist())) == 4
+    assert np.array_equal(models.make_beta_schedule(0, (1, 2), "custom", 2, [1.0, 2.0]), [1, 1, 2, 2])
+    with pytest.raises(ValueError):
+        models.make_beta_schedule(10, (0.1, 1.0), num_sweeps_per_beta=3)
+    with pytest.raises(ValueError):
+        models.make_beta_schedule(10, (0.0, 1.0))
+    with pytest.raises(ValueError):
+        models.make_beta_schedule(10, (0.1, 1.0), "exotic")
+
+
+def test_size_window_penalty_matches_bqm_lookalike():
+    """BQM_clustering.py:371-380: from_qubo + add_linear_inequality_constraint (slack bits)."""
+    fx = load_fixture("blobs")
+    keep = fx.nodes[:30]
+    ks = set(keep)
+    eu = [(u, v, w) for u, v, w in fx.edges if u in ks and v in ks]
+    Q = mo.q_bqm_3_cut_only(keep, eu)
+    bqm = BinaryQuadraticModel.from_qubo(Q)
+    slack = bqm.add_linear_inequality_constraint([(v, 1) for v in bqm.variables], lb=3, ub=30 / 6,
+                                                 lagrange_multiplier=0.7, label="c1_constraint")
+    assert [c for _, c in slack] == [-1, -1]                  # span 5 - 3 = 2 -> coefficients 1, 1
+    base = models.qubo_dict_to_model(Q)
+    pen = models.add_size_window_penalty(base, lb=3, ub=30 / 6, lagrange_multiplier=0.7)
+    assert pen.num_variables == base.num_variables + 2
+    rng = np.random.RandomState(4)
+    for _ in range(10):
+        z = rng.randint(0, 2, size=pen.num_variables)
+        sample = dict(zip(pen.variables, z.tolist()))
+        assert pen.energies(z[None, :])[0] == pytest.approx(bqm.energy(sample), rel=1e-10, abs=1e-9)
+    # feasible point (4 ones, slack = 1): zero penalty
+    z = np.zeros(pen.num_variables, dtype=int)
+    z[:4] = 1
+    z[base.num_variables] = 1
+    cut_only = base.energies(z[None, :base.num_variables])[0]
+    assert pen.energies(z[None, :])[0] == pytest.approx(cut_only, abs=1e-9)
+
+
+def test_synthetic_snn_shape():
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, truth = graphs.synthetic_snn(300, 5, 15, 15, 4, seed=1)
+    assert len(nodes) == 300 and nodes[0] == "0"
+    deg = np.bincount(np.concatenate([eu, ev]), minlength=300)
+    assert deg.max() <= 15                                       # trim honoured
+    allowed = {s / (10 - s) for s in range(1, 6)}
+    assert all(min(abs(x - a) for a in allowed) < 1e-12 for x in set(w.tolist()))
+    assert np.all(eu < ev)
+    G = graphs.EdgeListGraph(nodes, eu, ev, w)
+    Gn = graphs.graph_from_edges(nodes, eu, ev, w)
+    assert G.size(weight="weight") == pytest.approx(Gn.size(weight="weight"), rel=1e-13)
+    a = models.build_bqm_qubo(G, 0.05)
+    b = models.build_bqm_qubo(Gn, 0.05)
+    assert np.allclose(a.dense_Qs(), b.dense_Qs(), rtol=1e-13)
