@@ -76,6 +76,13 @@ int mi_sa_problem_create_potts_csr_f32(const int32_t *rowptr, const int32_t *col
 int mi_sa_problem_destroy(mi_sa_problem *p);
 int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases, int *device);
 
+/* Tuning switches that never change results: "pace" (default 1) holds the replicas of one XCD together
+ * at sweep boundaries so that their Q-row reads share that XCD's L2. */
+int mi_sa_set_option(mi_sa_problem *p, const char *key, long value);
+
+/* Diagnostic: copies the first `words` pacing words of the last launch (layout in mi_sa.hip). */
+int mi_sa_debug_pace(mi_sa_problem *p, unsigned int *out, int words);
+
 /* ---- the anneal (replaces the sampler call itself) ------------------------------------------- */
 
 /* R independent Metropolis chains x num_sweeps sweeps, one beta per sweep (betas[num_sweeps]).

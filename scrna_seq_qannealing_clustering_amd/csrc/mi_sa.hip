@@ -29,7 +29,7 @@
 
 #include "../../include/mi_sa.h"
 
-namespace {
+namespace mi_sa_impl {
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -123,6 +123,72 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sweep pacing (speed only, never correctness)
+// ------------------------------------------------------------------------------------------------
+// Replicas visit the rows of Q in the same order but accept different flips, so they drift apart and
+// their row fetches stop sharing the XCD's 4 MiB L2 (Q is ~30 MB): every fetch then comes from
+// Infinity Cache / HBM.  Holding the replicas of ONE XCD together at each sweep boundary keeps them
+// inside a window of a few hundred rows, which the L2 holds.  No data passes through this rendezvous:
+// results are identical with it on, off, or timing out -- every wait is bounded by a wall-clock
+// limit, so a launch whose waves are not all resident only loses time.
+//   pace[0]            waves started (launch-wide)
+//   pace[1]            pacing disabled (the start rendezvous timed out)
+//   pace[2]            sweep waits that hit their time limit (diagnostic)
+//   pace[32*(1+x)]     waves living on XCD x          (one 128-byte line per XCD)
+//   pace[32*(1+x)+1]   sweep arrivals on XCD x (monotonic)
+constexpr int kPaceWords = 32 * 9;
+constexpr long long kPaceStartTicks = 400000;   // 4 ms of the 100 MHz realtime clock
+constexpr long long kPaceSweepTicks = 200000;   // 2 ms
+
+__device__ __forceinline__ unsigned int pace_load(const unsigned int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// returns the XCD population, or 0 when pacing is off for this launch
+__device__ __forceinline__ unsigned int sweep_pace_begin(unsigned int *pace, unsigned int total_waves,
+                                                         unsigned int &xcc)
+{
+    if (!pace) return 0;
+    xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID[3:0]
+    unsigned int pop = 0;
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&pace[32 * (1 + xcc)], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        atomicAdd(&pace[0], 1u);
+        const long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool ok = true;
+        while (pace_load(&pace[0]) < total_waves) {
+            if (pace_load(&pace[1]) != 0 ||
+                (long long)__builtin_amdgcn_s_memrealtime() - t0 > kPaceStartTicks) {
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (!ok) __hip_atomic_store(&pace[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else pop = pace_load(&pace[32 * (1 + xcc)]);
+    }
+    return (unsigned int)__builtin_amdgcn_readfirstlane((int)pop);
+}
+
+__device__ __forceinline__ void sweep_pace_arrive_wait(unsigned int *pace, unsigned int xcc,
+                                                       unsigned int pop, unsigned int sweeps_done)
+{
+    if ((threadIdx.x & 63) == 0) {
+        unsigned int *arr = &pace[32 * (1 + xcc) + 1];
+        atomicAdd(arr, 1u);
+        const unsigned int target = pop * sweeps_done;
+        const long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (pace_load(arr) < target) {
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > kPaceSweepTicks) { atomicAdd(&pace[2], 1u); break; }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    // the other 63 lanes re-converge with lane 0 here (same wave): nothing else to do
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1: dense binary chain, one wavefront per replica, fields in VGPRs
 // ------------------------------------------------------------------------------------------------
 struct DenseArgs {
@@ -133,6 +199,7 @@ struct DenseArgs {
     uint8_t *states;        // R x n
     double *energy;         // R
     unsigned long long *stats;  // [0] proposals [1] accepted [2] bytes
+    unsigned int *pace;     // sweep pacing words (see sweep_pace_*), zeroed per launch; nullable
     double offset;
     int n, R, num_sweeps, resync;
     uint32_t replica_offset, seed_lo, seed_hi;
@@ -179,7 +246,7 @@ __device__ __forceinline__ void dense_field_init(float (&f)[NT], __amdgpu_buffer
         while (m) {
             const int l = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
-            dense_add_row<NT>(f, rsrc, (t < 0) ? n : t * 64 + l, lane, 1.0f);
+            dense_add_row<NT>(f, rsrc, (t < 0) ? n : t * 64 + l, lane, 1.0f);   // n = index of the diagonal row
         }
     }
 }
@@ -193,9 +260,11 @@ __global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
     const uint32_t g = a.replica_offset + (uint32_t)r;
     const int n = a.n;
 
-    // whole permuted matrix ((n+1) rows) behind one buffer descriptor built from kernel arguments
+    // whole permuted matrix behind one buffer descriptor built from kernel arguments: rows
+    // 0..64*slots-1 (zero rows past n), then the diagonal as one more row
+    const int diag_row = ((n + 63) >> 6) * 64;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.Qp), 0, (n + 1) * (NT * 64 * 4), 0x00020000);
+        const_cast<float *>(a.Qp), 0, (diag_row + 1) * (NT * 64 * 4), 0x00020000);
 
     float f[NT];
     uint64_t xb = 0;                            // bit t = x[64 t + lane]
@@ -220,13 +289,16 @@ __global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
         }
     }
 
+    unsigned int xcc = 0;
+    const unsigned int pace_pop = sweep_pace_begin(a.pace, (unsigned int)a.R, xcc);
+
     unsigned long long accepted = 0;
     int until_resync = a.resync;
     // s == num_sweeps is the epilogue pass: exact fields from the final state, no sweep.
     for (int s = 0; s <= a.num_sweeps; ++s) {
         bool init_now = (s == 0) || (s == a.num_sweeps);
         if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
-        if (init_now) dense_field_init<NT>(f, rsrc, n, xb, lane);
+        if (init_now) dense_field_init<NT>(f, rsrc, diag_row, xb, lane);
         if (s == a.num_sweeps) break;
         // temperature of this sweep as a scalar (SGPR) operand
         const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
@@ -261,13 +333,245 @@ __global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
                 }
             }
         });
+        if (pace_pop) sweep_pace_arrive_wait(a.pace, xcc, pace_pop, (unsigned int)(s + 1));
     }
 
     // E = 1/2 sum x_i (diag_i + f_i) in fp64 (f is exact for the final state here)
     float dg[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) dg[t] = 0.0f;
-    dense_add_row<NT>(dg, rsrc, n, lane, 1.0f);
+    dense_add_row<NT>(dg, rsrc, diag_row, lane, 1.0f);
+    double e = 0.0;
+    uint8_t *dst = a.states + (size_t)r * n + lane;
+    static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const bool on = (xb >> t) & 1ull;
+        if (t * 64 + lane < n) {
+            dst[t * 64] = on ? 1 : 0;
+            if (on) e += 0.5 * ((double)dg[t] + (double)f[t]);
+        }
+    });
+    e = wave_sum_f64(e);
+    if (lane == 0) {
+        a.energy[r] = e + a.offset;
+        atomicAdd(&a.stats[1], accepted);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1w: dense binary chain, one WORKGROUP of 16 wavefronts = 16 replicas sharing Q rows through LDS
+// ------------------------------------------------------------------------------------------------
+// Same chain as k_anneal_dense (bit-identical results), different data movement.  All replicas visit
+// the rows of Q in the same order, so a workgroup streams Q ONCE per sweep through an LDS ring and
+// every accepted flip of its 16 replicas reads its row from LDS (ds_read_b128, conflict-free:
+// 16 B/lane consecutive) instead of fetching 11 KB from L2 / Infinity Cache per flip.  HBM-side
+// traffic drops from (accepted flips x row) to (rows per sweep) per workgroup, i.e. by
+// 16 x acceptance rate, and no longer depends on the acceptance rate at all.
+//   ring: U units of GR rows (row = NT*256 bytes, slot-permuted like the global matrix), filled by
+//         LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave-instruction, no VGPRs), unit u+U-1
+//         issued when unit u starts, retired with a COUNTED s_waitcnt vmcnt + raw s_barrier so
+//         (U-2) units stay in flight across every barrier.
+//   lockstep: the 16 waves rendezvous once per unit (GR rows); inside a unit each wave runs its own
+//         accept/commit loop on the unit's rows.
+constexpr int kWgWaves = 16;
+constexpr int kLdsBytes = 160 * 1024;
+
+template <int NT, int GR>
+struct WgCfg {
+    static constexpr int ROWB = NT * 256;
+    static constexpr int UNITB = GR * ROWB;
+    static constexpr int G = NT / 4;                    // 1 KiB pieces per row (<= 16)
+    static constexpr int Ufit = kLdsBytes / UNITB;
+    static constexpr int Ucap = 2 + 60 / GR;            // keeps (U-2)*GR within the 6-bit vmcnt
+    static constexpr int U = Ufit < Ucap ? Ufit : Ucap;
+    static constexpr bool ok = U >= 3 && (64 % GR) == 0;
+};
+
+// f (+)= s * row, the row read from the LDS ring (ds_read_b128, 16 B/lane consecutive: conflict-free).
+// Done in two halves with a scheduling fence between them: LDS latency is short, and holding the
+// whole row in registers at once (NT more VGPRs) is what made this kernel spill.
+template <int NT>
+__device__ __forceinline__ void dense_add_row_lds(float (&f)[NT], const char *row, int lane, float s)
+{
+    constexpr int G = NT / 4, H = (G + 1) / 2;
+    const char *p = row + lane * 16;
+    {
+        f32x4 q[H];
+#pragma unroll
+        for (int g = 0; g < H; ++g) q[g] = *reinterpret_cast<const f32x4 *>(p + g * 1024);
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+            f[4 * g + 0] = __fmaf_rn(s, q[g].x, f[4 * g + 0]);
+            f[4 * g + 1] = __fmaf_rn(s, q[g].y, f[4 * g + 1]);
+            f[4 * g + 2] = __fmaf_rn(s, q[g].z, f[4 * g + 2]);
+            f[4 * g + 3] = __fmaf_rn(s, q[g].w, f[4 * g + 3]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G > H) {
+        f32x4 q[G - H];
+#pragma unroll
+        for (int g = H; g < G; ++g) q[g - H] = *reinterpret_cast<const f32x4 *>(p + g * 1024);
+#pragma unroll
+        for (int g = H; g < G; ++g) {
+            f[4 * g + 0] = __fmaf_rn(s, q[g - H].x, f[4 * g + 0]);
+            f[4 * g + 1] = __fmaf_rn(s, q[g - H].y, f[4 * g + 1]);
+            f[4 * g + 2] = __fmaf_rn(s, q[g - H].z, f[4 * g + 2]);
+            f[4 * g + 3] = __fmaf_rn(s, q[g - H].w, f[4 * g + 3]);
+        }
+    }
+}
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from (buffer base + voff + soff) to lds_dst + lane*16
+// (buffer_load_dwordx4 ... lds).  Kept in a non-template __device__ function: inside a kernel TEMPLATE
+// the builtin makes hipcc silently drop the kernel's host-side launch stub (undefined symbol at load).
+__device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char *lds_dst, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 16,
+                                             voff, soff, 0, 0);
+}
+
+template <int NT, int GR>
+__global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
+{
+    using C = WgCfg<NT, GR>;
+    __shared__ __attribute__((aligned(16))) char ring[C::U * C::UNITB];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = blockIdx.x * kWgWaves + wave;
+    const bool active = r < a.R;                 // idle waves still take part in DMA and barriers
+    const uint32_t g = a.replica_offset + (uint32_t)r;
+    const int n = a.n;
+    const int slots_used = (n + 63) >> 6;
+    const int units_per_sweep = slots_used * (64 / GR);
+    const long long total_units = (long long)a.num_sweeps * units_per_sweep;
+
+    // rows 0..64*slots_used-1 (zero rows past n) + the diagonal row at index 64*slots_used
+    const int diag_row = slots_used * 64;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.Qp), 0, (diag_row + 1) * C::ROWB, 0x00020000);
+
+    float f[NT];
+    uint64_t xb = 0;
+    if (active) {
+        if (a.init) {
+            const uint8_t *src = a.init + (size_t)r * n;
+#pragma unroll 1
+            for (int t = 0; t < NT; ++t) {
+                const int i = t * 64 + lane;
+                if (i < n && src[i]) xb |= (1ull << t);
+            }
+        } else {
+#pragma unroll 1
+            for (int g4 = 0; g4 < NT / 4; ++g4) {
+                uint32_t w[4];
+                philox4x32_10((uint32_t)(g4 * 64 + lane), 0u, g, 1u, a.seed_lo, a.seed_hi, w);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int t = 4 * g4 + c;
+                    if (t * 64 + lane < n) xb |= ((uint64_t)(w[c] >> 31) << t);
+                }
+            }
+        }
+    }
+
+    // sweep pacing across the workgroups of one XCD (wave 0 of each workgroup takes part; the other
+    // waves are held by the next unit barrier): keeps the 32 rings of an XCD within the L2 window
+    unsigned int xcc = 0;
+    unsigned int pace_pop = 0;
+    if (wave == 0) pace_pop = sweep_pace_begin(a.pace, gridDim.x, xcc);
+
+    // ---- ring bookkeeping (all wave-uniform) ----
+    long long issued = 0;                        // units whose DMA has been issued
+    int issue_row = 0;                           // first row of the next unit to issue
+    int issue_slot = 0;                          // ring slot of the next unit to issue
+    int cur_slot = 0;                            // ring slot of the unit being processed
+    long long processed = 0;                     // units fully processed
+    auto issue_unit = [&]() {
+        if (issued < total_units) {
+            if (wave < C::G) {
+#pragma unroll
+                for (int k = 0; k < GR; ++k)
+                    lds_dma_16(rsrc, ring + issue_slot * C::UNITB + k * C::ROWB + wave * 1024, lane * 16,
+                               (issue_row + k) * C::ROWB + wave * 1024);
+            }
+            ++issued;
+            issue_row += GR;
+            if (issue_row >= units_per_sweep * GR) issue_row = 0;
+            issue_slot = (issue_slot + 1 == C::U) ? 0 : issue_slot + 1;
+        }
+    };
+
+    unsigned long long accepted = 0;
+    int until_resync = a.resync;
+    for (int s = 0; s <= a.num_sweeps; ++s) {
+        bool init_now = (s == 0) || (s == a.num_sweeps);
+        if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
+        if (init_now && active) dense_field_init<NT>(f, rsrc, diag_row, xb, lane);
+        if (s == a.num_sweeps) break;
+        if (s == 0) {
+            // everything above used ordinary loads; from here on only LDS-DMA is in the VM queue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int u = 0; u < C::U - 1; ++u) issue_unit();
+        }
+        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+        uint32_t w[4];
+        static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            int nn = n, ln = lane;
+            asm volatile("" : "+s"(nn));
+            asm volatile("" : "+v"(ln));
+            const int left = nn - t * 64;
+            if (left > 0) {                     // wave-uniform, identical in every wave of the block
+                if constexpr ((t & 3) == 0)
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + ln), (uint32_t)s, g, 0u, a.seed_lo,
+                                  a.seed_hi, w);
+                float thr = neglog_u(w[t & 3]) * T;
+                if (ln >= left || !active) thr = -INFINITY;
+                float sg = ((xb >> t) & 1ull) ? -1.0f : 1.0f;
+                uint64_t todo = ~0ull;
+#pragma unroll 1
+                for (int j = 0; j < 64 / GR; ++j) {
+                    // retire unit (this wave's pieces), rendezvous, refill the slot just vacated
+                    // counted wait: (U-2) younger units stay in flight -- valid only while that many
+                    // younger units HAVE been issued; at the tail of the run drain everything
+                    if (issued - processed - 1 >= C::U - 2) {
+                        if (wave < C::G)
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::U - 2) * GR) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue_unit();
+                    const uint64_t umask = (GR == 64) ? ~0ull : (((1ull << GR) - 1ull) << (j * GR));
+                    const char *unit = ring + cur_slot * C::UNITB;
+                    while (true) {
+                        const float dE = sg * f[t];
+                        const uint64_t m = __ballot(dE < thr) & todo & umask;
+                        if (m == 0) break;
+                        const int l = __ffsll((unsigned long long)m) - 1;
+                        todo = (l == 63) ? 0ull : (~0ull << (l + 1));
+                        const float sl = readlane_f(sg, l);
+                        if (ln == l) { sg = -sg; xb ^= (1ull << t); }
+                        dense_add_row_lds<NT>(f, unit + (l - j * GR) * C::ROWB, ln, sl);
+                        ++accepted;
+                    }
+                    cur_slot = (cur_slot + 1 == C::U) ? 0 : cur_slot + 1;
+                    ++processed;
+                }
+            }
+        });
+        if (pace_pop) sweep_pace_arrive_wait(a.pace, xcc, pace_pop, (unsigned int)(s + 1));
+    }
+
+    if (!active) return;
+    float dg[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dg[t] = 0.0f;
+    dense_add_row<NT>(dg, rsrc, diag_row, lane, 1.0f);
     double e = 0.0;
     uint8_t *dst = a.states + (size_t)r * n + lane;
     static_for<0, NT>([&](auto tc) {
@@ -337,7 +641,8 @@ __global__ void __launch_bounds__(256) k_best(const double *__restrict__ energy,
     if ((threadIdx.x & 63) == 0) atomicMin(out_key, best);
 }
 
-}  // namespace
+}  // namespace mi_sa_impl
+using namespace mi_sa_impl;
 
 // ================================================================================================
 // host side
@@ -361,6 +666,11 @@ struct mi_sa_problem {
     void *d_states = nullptr;
     double *d_energy = nullptr;
     unsigned long long *d_stats = nullptr;   // 4 words: proposals, accepted, bytes, best-key
+    unsigned int *d_pace = nullptr;          // kPaceWords per launch chunk
+    int opt_pace = 1;                        // sweep pacing on/off (speed only)
+    int opt_variant = 0;                     // 0 auto, 1 wave-per-replica (K1), 2 workgroup/LDS ring (K1w)
+    int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 1/2/4
+    int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
     size_t state_elem = 1;
 };
 
@@ -398,17 +708,88 @@ int ensure_run_buffers(mi_sa_problem *p, int R, int num_sweeps, bool need_init)
     return MI_OK;
 }
 
+constexpr int kMaxChunks = 64;
+
+// Launches the anneal in chunks of at most `resident` replicas (= wavefronts), so that every wave of
+// a launch is co-resident and the sweep pacing rendezvous can complete; chunks run back to back on
+// the stream.  Each chunk gets its own zeroed pacing words.
 template <int NT>
-void launch_dense(const DenseArgs &a, hipStream_t st)
+int launch_dense(mi_sa_problem *p, DenseArgs a, hipStream_t st)
 {
-    const int blocks = (a.R + 3) / 4;
-    hipLaunchKernelGGL(k_anneal_dense<NT>, dim3(blocks), dim3(256), 0, st, a);
+    if (p->resident_waves == 0) {
+        int blocks_per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_anneal_dense<NT>, 256, 0));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device));
+        p->resident_waves = blocks_per_cu * cus * 4;
+        if (p->resident_waves < 4) return fail(MI_EHIP, "anneal kernel cannot be resident (occupancy 0)");
+    }
+    const int total = a.R;
+    const uint32_t base_offset = a.replica_offset;
+    const uint8_t *init0 = a.init;
+    uint8_t *states0 = a.states;
+    double *energy0 = a.energy;
+    int chunk = p->resident_waves;
+    if ((total + chunk - 1) / chunk > kMaxChunks) chunk = (total + kMaxChunks - 1) / kMaxChunks;
+    const bool pace = p->opt_pace && a.num_sweeps > 1;
+    if (pace)
+        HIP_TRY(hipMemsetAsync(p->d_pace, 0, kMaxChunks * kPaceWords * sizeof(unsigned int), st));
+    int c = 0;
+    for (int lo = 0; lo < total; lo += chunk, ++c) {
+        const int cnt = total - lo < chunk ? total - lo : chunk;
+        a.R = cnt;
+        a.replica_offset = base_offset + (uint32_t)lo;
+        a.init = init0 ? init0 + (size_t)lo * a.n : nullptr;
+        a.states = states0 + (size_t)lo * a.n;
+        a.energy = energy0 + lo;
+        a.pace = (pace && cnt <= p->resident_waves) ? p->d_pace + (size_t)c * kPaceWords : nullptr;
+        hipLaunchKernelGGL(k_anneal_dense<NT>, dim3((cnt + 3) / 4), dim3(256), 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return MI_OK;
 }
 
-int dispatch_dense(int NT, const DenseArgs &a, hipStream_t st)
+template <int NT, int GR>
+int launch_dense_wg(mi_sa_problem *p, DenseArgs a, hipStream_t st)
 {
-    switch (NT) {
-#define MI_CASE(N) case N: launch_dense<N>(a, st); return MI_OK;
+    if constexpr (WgCfg<NT, GR>::ok) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device));
+        const int blocks = (a.R + kWgWaves - 1) / kWgWaves;
+        a.pace = nullptr;
+        if (p->opt_pace && a.num_sweeps > 1 && blocks <= cus) {     // one 160 KB workgroup per CU
+            HIP_TRY(hipMemsetAsync(p->d_pace, 0, kPaceWords * sizeof(unsigned int), st));
+            a.pace = p->d_pace;
+        }
+        hipLaunchKernelGGL((k_anneal_dense_wg<NT, GR>), dim3((a.R + kWgWaves - 1) / kWgWaves), dim3(1024), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    } else {
+        return fail(MI_EUNSUPPORTED, "LDS ring does not fit for NT=%d unit_rows=%d", NT, GR);
+    }
+}
+
+template <int NT>
+int launch_dense_any(mi_sa_problem *p, const DenseArgs &a, hipStream_t st)
+{
+    int variant = p->opt_variant;
+    if (variant == 0) variant = (a.R >= 2 * kWgWaves && a.num_sweeps > 0) ? 2 : 1;
+    if (variant == 2) {
+        int gr = p->opt_unit_rows ? p->opt_unit_rows : 2;
+        if (gr == 4 && !WgCfg<NT, 4>::ok) gr = 2;
+        if (gr == 2 && !WgCfg<NT, 2>::ok) gr = 1;
+        switch (gr) {
+            case 1: return launch_dense_wg<NT, 1>(p, a, st);
+            case 2: return launch_dense_wg<NT, 2>(p, a, st);
+            case 4: return launch_dense_wg<NT, 4>(p, a, st);
+        }
+    }
+    return launch_dense<NT>(p, a, st);
+}
+
+int dispatch_dense(mi_sa_problem *p, const DenseArgs &a, hipStream_t st)
+{
+    switch (p->NT) {
+#define MI_CASE(N) case N: return launch_dense_any<N>(p, a, st);
 #ifdef MI_SA_DEV_NT   /* development builds: only NT=4 and one large size, to cut compile time */
         MI_CASE(4) MI_CASE(MI_SA_DEV_NT)
 #else
@@ -418,7 +799,7 @@ int dispatch_dense(int NT, const DenseArgs &a, hipStream_t st)
 #endif
 #undef MI_CASE
     }
-    return fail(MI_EUNSUPPORTED, "dense kernel not built for NT=%d", NT);
+    return fail(MI_EUNSUPPORTED, "dense kernel not built for NT=%d", p->NT);
 }
 
 constexpr int kMaxDenseN = 64 * 64;
@@ -461,6 +842,7 @@ static int problem_common_init(mi_sa_problem *p, int device)
     HIP_TRY(hipEventCreate(&p->ev1));
     HIP_TRY(hipMalloc((void **)&p->d_stats, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(p->d_stats, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&p->d_pace, kMaxChunks * kPaceWords * sizeof(unsigned int)));
     return MI_OK;
 }
 
@@ -482,7 +864,8 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
     p->NT = ((slots + 3) / 4) * 4;
     const size_t stride = (size_t)p->NT * 64;
     // host-side permute: Qp[i][(g*64+lane)*4+c] = 2*Qs[i][64*(4g+c)+lane] (0 on diagonal / padding)
-    std::vector<float> hp((size_t)(n + 1) * stride, 0.0f);
+    const int diag_row = slots * 64;
+    std::vector<float> hp((size_t)(diag_row + 1) * stride, 0.0f);
     for (int i = 0; i < n; ++i) {
         const float *row = Qs + (size_t)i * n;
         float *dst = hp.data() + (size_t)i * stride;
@@ -491,7 +874,7 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
             const int t = j >> 6, lane = j & 63;
             dst[((size_t)(t >> 2) * 64 + lane) * 4 + (t & 3)] = row[j] + row[j];
         }
-        hp[(size_t)n * stride + ((size_t)((i >> 6) >> 2) * 64 + (i & 63)) * 4 + ((i >> 6) & 3)] = row[i];
+        hp[(size_t)diag_row * stride + ((size_t)((i >> 6) >> 2) * 64 + (i & 63)) * 4 + ((i >> 6) & 3)] = row[i];
     }
     rc = [&]() -> int {
         HIP_TRY(hipMalloc((void **)&p->d_Qp, hp.size() * sizeof(float)));
@@ -520,7 +903,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -538,6 +921,25 @@ int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases
     if (num_cases) *num_cases = p->K;
     if (device) *device = p->device;
     return MI_OK;
+}
+
+int mi_sa_debug_pace(mi_sa_problem *p, unsigned int *out, int words)
+{
+    if (!p || !out) return fail(MI_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (words > kPaceWords) words = kPaceWords;
+    HIP_TRY(hipMemcpy(out, p->d_pace, (size_t)words * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
+{
+    if (!p || !key) return fail(MI_EINVAL, "NULL argument");
+    if (!strcmp(key, "pace")) { p->opt_pace = value != 0; return MI_OK; }
+    if (!strcmp(key, "variant") && value >= 0 && value <= 2) { p->opt_variant = (int)value; return MI_OK; }
+    if (!strcmp(key, "unit_rows") && (value == 0 || value == 1 || value == 2 || value == 4)) { p->opt_unit_rows = (int)value; return MI_OK; }
+    return fail(MI_EINVAL, "unknown option '%s'", key);
 }
 
 int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
@@ -567,13 +969,12 @@ int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweep
         DenseArgs a;
         a.Qp = p->d_Qp; a.temps = p->d_temps;
         a.init = init ? (const uint8_t *)p->d_init : nullptr;
-        a.states = (uint8_t *)p->d_states; a.energy = p->d_energy; a.stats = p->d_stats;
+        a.states = (uint8_t *)p->d_states; a.energy = p->d_energy; a.stats = p->d_stats; a.pace = nullptr;
         a.offset = p->offset; a.n = p->n; a.R = R; a.num_sweeps = num_sweeps; a.resync = resync_interval;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
-        rc = dispatch_dense(p->NT, a, p->stream);
+        rc = dispatch_dense(p, a, p->stream);
         if (rc) return rc;
-        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
     } else {
         return fail(MI_EUNSUPPORTED, "kind %d not built yet", p->kind);

@@ -85,6 +85,14 @@ class Problem:
     def __exit__(self, *exc):
         self.close()
 
+    def set_option(self, key: str, value: int):
+        _lib.check(_lib.load().mi_sa_set_option(self._h, key.encode(), int(value)))
+
+    def debug_pace(self, words: int = 288):
+        out = np.zeros(words, dtype=np.uint32)
+        _lib.check(_lib.load().mi_sa_debug_pace(self._h, _ptr(out, C.c_uint32), words))
+        return out
+
     # -- the anneal -----------------------------------------------------------------------------
     @property
     def state_dtype(self):
