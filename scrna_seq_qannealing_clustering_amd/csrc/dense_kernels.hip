@@ -1,0 +1,500 @@
+// dense_kernels.hip -- the dense-QUBO anneal kernels (K1 wave-per-replica, K1w workgroup/LDS ring) and
+// their launcher for ONE field-register count NT = MI_NT (n <= 64*NT).  Compiled once per NT so that the
+// sixteen sizes build in parallel (each is a fully unrolled ~10k-instruction kernel).
+//
+// Chain specification, layouts and the reference call sites served: see mi_sa.hip / DESIGN.md.
+#include "mi_sa_device.h"
+
+#ifndef MI_NT
+#error "compile with -DMI_NT=<4,8,...,64>"
+#endif
+
+namespace mi_sa_impl {
+
+// f (+)= s * Q2[row].  The row is fetched with NT/4 buffer loads of 16 B/lane (1 KiB per
+// wave-instruction, fully coalesced): descriptor in SGPRs, ONE VGPR of addressing (lane*16), the
+// wave-uniform row offset in soffset -- flat global loads cost three 64-bit VGPR address pairs here
+// and push the kernel into spilling its field registers.
+template <int NT>
+__device__ __forceinline__ void dense_add_row(float (&f)[NT], __amdgpu_buffer_rsrc_t rsrc, int row,
+                                              int lane, float s)
+{
+    const int voff = lane * 16;
+    const int soff = row * (NT * 64 * 4);
+    u32x4 q[NT / 4];
+#pragma unroll
+    for (int g = 0; g < NT / 4; ++g)
+        q[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + g * 1024, 0);
+#pragma unroll
+    for (int g = 0; g < NT / 4; ++g) {
+        f[4 * g + 0] = __fmaf_rn(s, __uint_as_float(q[g].x), f[4 * g + 0]);
+        f[4 * g + 1] = __fmaf_rn(s, __uint_as_float(q[g].y), f[4 * g + 1]);
+        f[4 * g + 2] = __fmaf_rn(s, __uint_as_float(q[g].z), f[4 * g + 2]);
+        f[4 * g + 3] = __fmaf_rn(s, __uint_as_float(q[g].w), f[4 * g + 3]);
+    }
+}
+
+// f = diag ; then add row j for every j with x_j = 1, ascending j.  The diagonal is stored as row n
+// of the permuted matrix, so every global access of the kernel goes through dense_add_row
+// (0 + 1*d = d exactly).
+template <int NT>
+__device__ __forceinline__ void dense_field_init(float (&f)[NT], __amdgpu_buffer_rsrc_t rsrc, int n,
+                                                 uint64_t xb, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t) f[t] = 0.0f;
+#pragma unroll 1
+    for (int t = -1; t < NT; ++t) {             // runtime loop: one copy of the row update
+        uint64_t m = (t < 0) ? 1ull : __ballot((xb >> t) & 1ull);
+        while (m) {
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            dense_add_row<NT>(f, rsrc, (t < 0) ? n : t * 64 + l, lane, 1.0f);   // n = index of the diagonal row
+        }
+    }
+}
+
+// Energy of the final state, E = sum_i x_i diag_i + 1/2 sum_{i,j} x_i x_j Q2_ij, with every fp32 matrix
+// entry added EXACTLY once into fp64 accumulators (lane l sums its own columns over all set rows; one
+// wave reduction at the end).  Independent of the cached fp32 fields, so the reported energies carry
+// no accumulated rounding of the chain.
+template <int NT>
+__device__ __forceinline__ double dense_energy_f64(__amdgpu_buffer_rsrc_t rsrc, int diag_row, uint64_t xb,
+                                                   int lane)
+{
+    constexpr int G = NT / 4;
+    const int voff = lane * 16;
+    double pair = 0.0, lin = 0.0;
+#pragma unroll 1
+    for (int t = -1; t < NT; ++t) {
+        uint64_t m = (t < 0) ? 1ull : __ballot((xb >> t) & 1ull);
+        while (m) {
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const int soff = ((t < 0) ? diag_row : t * 64 + l) * (NT * 256);
+            double acc = 0.0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + g * 1024, 0);
+                acc += ((xb >> (4 * g + 0)) & 1ull) ? (double)__uint_as_float(q.x) : 0.0;
+                acc += ((xb >> (4 * g + 1)) & 1ull) ? (double)__uint_as_float(q.y) : 0.0;
+                acc += ((xb >> (4 * g + 2)) & 1ull) ? (double)__uint_as_float(q.z) : 0.0;
+                acc += ((xb >> (4 * g + 3)) & 1ull) ? (double)__uint_as_float(q.w) : 0.0;
+            }
+            if (t < 0) lin = acc; else pair += acc;
+        }
+    }
+    return wave_sum_f64(lin + 0.5 * pair);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;                       // wave-uniform
+    const uint32_t g = a.replica_offset + (uint32_t)r;
+    const int n = a.n;
+
+    // whole permuted matrix behind one buffer descriptor built from kernel arguments: rows
+    // 0..64*slots-1 (zero rows past n), then the diagonal as one more row
+    const int diag_row = ((n + 63) >> 6) * 64;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.Qp), 0, (diag_row + 1) * (NT * 64 * 4), 0x00020000);
+
+    float f[NT];
+    uint64_t xb = 0;                            // bit t = x[64 t + lane]
+
+    if (a.init) {
+        const uint8_t *src = a.init + (size_t)r * n;
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            const int i = t * 64 + lane;
+            if (i < n && src[i]) xb |= (1ull << t);
+        }
+    } else {
+#pragma unroll 1
+        for (int g4 = 0; g4 < NT / 4; ++g4) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)(g4 * 64 + lane), 0u, g, 1u, a.seed_lo, a.seed_hi, w);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int t = 4 * g4 + c;
+                if (t * 64 + lane < n) xb |= ((uint64_t)(w[c] >> 31) << t);
+            }
+        }
+    }
+
+    unsigned int xcc = 0;
+    const unsigned int pace_pop = sweep_pace_begin(a.pace, (unsigned int)a.R, xcc);
+
+    unsigned long long accepted = 0;
+    int until_resync = a.resync;
+    for (int s = 0; s < a.num_sweeps; ++s) {
+        bool init_now = (s == 0);
+        if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
+        if (init_now) dense_field_init<NT>(f, rsrc, diag_row, xb, lane);
+        // temperature of this sweep as a scalar (SGPR) operand
+        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+        uint32_t w[4];
+        static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            // Opaque per-slot copies of n and lane: everything derived from them is then NOT
+            // loop-invariant for LICM, which otherwise hoists ~NT masks, NT lane offsets and NT/4
+            // Philox blocks out of the sweep loop and makes the kernel spill its field registers.
+            int nn = n, ln = lane;
+            asm volatile("" : "+s"(nn));
+            asm volatile("" : "+v"(ln));
+            const int left = nn - t * 64;       // variables remaining from this slot on (scalar)
+            if (left > 0) {                     // wave-uniform
+                if constexpr ((t & 3) == 0)
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + ln), (uint32_t)s, g, 0u, a.seed_lo,
+                                  a.seed_hi, w);
+                float thr = neglog_u(w[t & 3]) * T;
+                if (ln >= left) thr = -INFINITY;
+                float sg = ((xb >> t) & 1ull) ? -1.0f : 1.0f;
+                uint64_t todo = ~0ull;
+                while (true) {
+                    const float dE = sg * f[t];
+                    const uint64_t m = __ballot(dE < thr) & todo;
+                    if (m == 0) break;
+                    const int l = __ffsll((unsigned long long)m) - 1;
+                    todo = (l == 63) ? 0ull : (~0ull << (l + 1));
+                    const float sl = readlane_f(sg, l);
+                    if (ln == l) { sg = -sg; xb ^= (1ull << t); }
+                    dense_add_row<NT>(f, rsrc, t * 64 + l, ln, sl);
+                    ++accepted;
+                }
+            }
+        });
+        if (pace_pop) sweep_pace_arrive_wait(a.pace, xcc, pace_pop, (unsigned int)(s + 1));
+    }
+
+    // final states out; energies re-evaluated exactly (fp64 accumulation of the fp32 entries)
+    uint8_t *dst = a.states + (size_t)r * n + lane;
+    static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (t * 64 + lane < n) dst[t * 64] = ((xb >> t) & 1ull) ? 1 : 0;
+    });
+    const double e = dense_energy_f64<NT>(rsrc, diag_row, xb, lane);
+    if (lane == 0) {
+        a.energy[r] = e + a.offset;
+        atomicAdd(&a.stats[1], accepted);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1w: dense binary chain, one WORKGROUP of 16 wavefronts = 16 replicas sharing Q rows through LDS
+// ------------------------------------------------------------------------------------------------
+// Same chain as k_anneal_dense (bit-identical results), different data movement.  All replicas visit
+// the rows of Q in the same order, so a workgroup streams Q ONCE per sweep through an LDS ring and
+// every accepted flip of its 16 replicas reads its row from LDS (ds_read_b128, conflict-free:
+// 16 B/lane consecutive) instead of fetching 11 KB from L2 / Infinity Cache per flip.  HBM-side
+// traffic drops from (accepted flips x row) to (rows per sweep) per workgroup, i.e. by
+// 16 x acceptance rate, and no longer depends on the acceptance rate at all.
+//   ring: U units of GR rows (row = NT*256 bytes, slot-permuted like the global matrix), filled by
+//         LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave-instruction, no VGPRs), unit u+U-1
+//         issued when unit u starts, retired with a COUNTED s_waitcnt vmcnt + raw s_barrier so
+//         (U-2) units stay in flight across every barrier.
+//   lockstep: the 16 waves rendezvous once per unit (GR rows); inside a unit each wave runs its own
+//         accept/commit loop on the unit's rows.
+constexpr int kWgWaves = 16;
+constexpr int kLdsBytes = 160 * 1024;
+
+template <int NT, int GR>
+struct WgCfg {
+    static constexpr int ROWB = NT * 256;
+    static constexpr int UNITB = GR * ROWB;
+    static constexpr int G = NT / 4;                    // 1 KiB pieces per row (<= 16)
+    static constexpr int Ufit = kLdsBytes / UNITB;
+    static constexpr int Ucap = 2 + 60 / GR;            // keeps (U-2)*GR within the 6-bit vmcnt
+    static constexpr int U = Ufit < Ucap ? Ufit : Ucap;
+    static constexpr bool ok = U >= 3 && (64 % GR) == 0;
+};
+
+
+// f (+)= s * row, the row read from the LDS ring (ds_read_b128, 16 B/lane consecutive: conflict-free).
+//   * fields live as NT/2 register PAIRS so that each 16-byte piece is consumed by two v_pk_fma_f32;
+//   * pieces are visited starting with the one that holds slot T (rotation by T/4) and `after_first`
+//     runs right after it: the field of the slot being swept is final there, so the caller picks the
+//     NEXT flip while the rest of this row is still being added (shortens the serial flip chain);
+//   * a rolling window of W pieces is in flight (LDS latency is short; a whole row in registers at
+//     once is what made this kernel spill).
+template <int NT, int T, int W, typename F>
+__device__ __forceinline__ void dense_add_row_lds(f32x2 (&f)[NT / 2], const char *row_lane, float s,
+                                                  F &&after_first)
+{
+    constexpr int G = NT / 4, G0 = T / 4, WW = W < G ? W : G;
+    const f32x2 s2 = {s, s};
+    f32x4 q[WW];
+#pragma unroll
+    for (int k = 0; k < WW; ++k)
+        q[k] = *reinterpret_cast<const f32x4 *>(row_lane + ((G0 + k) % G) * 1024);
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const int g = (G0 + k) % G;
+        const f32x2 lo = {q[k % WW].x, q[k % WW].y}, hi = {q[k % WW].z, q[k % WW].w};
+        f[2 * g + 0] = __builtin_elementwise_fma(s2, lo, f[2 * g + 0]);
+        f[2 * g + 1] = __builtin_elementwise_fma(s2, hi, f[2 * g + 1]);
+        if (k + WW < G)
+            q[k % WW] = *reinterpret_cast<const f32x4 *>(row_lane + ((G0 + k + WW) % G) * 1024);
+        if (k == 0) after_first();
+    }
+}
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from (buffer base + voff + soff) to lds_dst + lane*16
+// (buffer_load_dwordx4 ... lds).  Kept in a non-template __device__ function: inside a kernel TEMPLATE
+// the builtin makes hipcc silently drop the kernel's host-side launch stub (undefined symbol at load).
+__device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char *lds_dst, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 16,
+                                             voff, soff, 0, 0);
+}
+
+template <int NT, int GR>
+__global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
+{
+    using C = WgCfg<NT, GR>;
+    __shared__ __attribute__((aligned(16))) char ring[C::U * C::UNITB];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = blockIdx.x * kWgWaves + wave;
+    const bool active = r < a.R;                 // idle waves still take part in DMA and barriers
+    const uint32_t g = a.replica_offset + (uint32_t)r;
+    const int n = a.n;
+    const int slots_used = (n + 63) >> 6;
+    const int units_per_sweep = slots_used * (64 / GR);
+    const int total_units = a.num_sweeps * units_per_sweep;      // host checks it fits an int
+
+    // rows 0..64*slots_used-1 (zero rows past n) + the diagonal row at index 64*slots_used
+    const int diag_row = slots_used * 64;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.Qp), 0, (diag_row + 1) * C::ROWB, 0x00020000);
+
+    f32x2 f[NT / 2];                            // field of slot t = f[t >> 1][t & 1]
+    uint64_t xb = 0;
+    if (active) {
+        if (a.init) {
+            const uint8_t *src = a.init + (size_t)r * n;
+#pragma unroll 1
+            for (int t = 0; t < NT; ++t) {
+                const int i = t * 64 + lane;
+                if (i < n && src[i]) xb |= (1ull << t);
+            }
+        } else {
+#pragma unroll 1
+            for (int g4 = 0; g4 < NT / 4; ++g4) {
+                uint32_t w[4];
+                philox4x32_10((uint32_t)(g4 * 64 + lane), 0u, g, 1u, a.seed_lo, a.seed_hi, w);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int t = 4 * g4 + c;
+                    if (t * 64 + lane < n) xb |= ((uint64_t)(w[c] >> 31) << t);
+                }
+            }
+        }
+    }
+
+    // sweep pacing across the workgroups of one XCD (wave 0 of each workgroup takes part; the other
+    // waves are held by the next unit barrier): keeps the 32 rings of an XCD within the L2 window
+    unsigned int xcc = 0;
+    unsigned int pace_pop = 0;
+    if (wave == 0) pace_pop = sweep_pace_begin(a.pace, gridDim.x, xcc);
+
+    // ---- ring bookkeeping (all wave-uniform) ----
+    // (kept in SGPRs by force: hipcc's uniformity analysis otherwise demotes them to VGPRs and wraps
+    // every LDS-DMA in a waterfall loop)
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    int issued = 0;                              // units whose DMA has been issued
+    int issue_row = 0;                           // first row of the next unit to issue
+    int issue_slot = 0;                          // ring slot of the next unit to issue
+    int cur_slot = 0;                            // ring slot of the unit being processed
+    int processed = 0;                           // units fully processed
+    auto issue_unit = [&]() {
+        if (issued < total_units) {
+            if (wave < C::G && !(a.debug & 1)) {
+#pragma unroll
+                for (int k = 0; k < GR; ++k)
+                    lds_dma_16(rsrc, ring + issue_slot * C::UNITB + k * C::ROWB + wave * 1024, lane * 16,
+                               (issue_row + k) * C::ROWB + wave * 1024);
+            }
+            issued = uni(issued + 1);
+            issue_row = uni(issue_row + GR >= units_per_sweep * GR ? 0 : issue_row + GR);
+            issue_slot = uni((issue_slot + 1 == C::U) ? 0 : issue_slot + 1);
+        }
+    };
+
+    unsigned long long accepted = 0;
+    int until_resync = a.resync;
+    for (int s = 0; s < a.num_sweeps; ++s) {
+        bool init_now = (s == 0);
+        if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
+        if (init_now && active) {
+            float fs[NT];
+            dense_field_init<NT>(fs, rsrc, diag_row, xb, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) f[t >> 1][t & 1] = fs[t];
+        }
+        if (s == 0) {
+            // everything above used ordinary loads; from here on only LDS-DMA is in the VM queue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int u = 0; u < C::U - 1; ++u) issue_unit();
+        }
+        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+        uint32_t w[4];
+        static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            int nn = n, ln = lane;
+            asm volatile("" : "+s"(nn));
+            asm volatile("" : "+v"(ln));
+            const int left = nn - t * 64;
+            if (left > 0) {                     // wave-uniform, identical in every wave of the block
+                if constexpr ((t & 3) == 0)
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + ln), (uint32_t)s, g, 0u, a.seed_lo,
+                                  a.seed_hi, w);
+                float thr = neglog_u(w[t & 3]) * T;
+                if (ln >= left || !active || (a.debug & 2)) thr = -INFINITY;
+                float sg = ((xb >> t) & 1ull) ? -1.0f : 1.0f;
+                uint64_t todo = ~0ull;
+#pragma unroll 1
+                for (int j = 0; j < 64 / GR; ++j) {
+                    // retire unit (this wave's pieces), rendezvous, refill the slot just vacated
+                    // counted wait: (U-2) younger units stay in flight -- valid only while that many
+                    // younger units HAVE been issued; at the tail of the run drain everything
+                    if (issued - processed - 1 >= C::U - 2) {
+                        if (wave < C::G)
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::U - 2) * GR) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue_unit();
+                    const uint64_t umask = (GR == 64) ? ~0ull : (((1ull << GR) - 1ull) << (j * GR));
+                    const char *unit = ring + cur_slot * C::UNITB;
+                    uint64_t m = __ballot(sg * f[t >> 1][t & 1] < thr) & todo & umask;
+                    while (m != 0) {
+                        const int l = __ffsll((unsigned long long)m) - 1;
+                        todo = (l == 63) ? 0ull : (~0ull << (l + 1));
+                        const float sl = readlane_f(sg, l);
+                        if (ln == l) { sg = -sg; xb ^= (1ull << t); }
+                        dense_add_row_lds<NT, t, 8>(f, unit + (l - j * GR) * C::ROWB + ln * 16, sl, [&]() {
+                            m = __ballot(sg * f[t >> 1][t & 1] < thr) & todo & umask;
+                        });
+                        ++accepted;
+                    }
+                    cur_slot = uni((cur_slot + 1 == C::U) ? 0 : cur_slot + 1);
+                    processed = uni(processed + 1);
+                }
+            }
+        });
+        if (pace_pop) sweep_pace_arrive_wait(a.pace, xcc, pace_pop, (unsigned int)(s + 1));
+    }
+
+    if (!active) return;
+    uint8_t *dst = a.states + (size_t)r * n + lane;
+    static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (t * 64 + lane < n) dst[t * 64] = ((xb >> t) & 1ull) ? 1 : 0;
+    });
+    const double e = dense_energy_f64<NT>(rsrc, diag_row, xb, lane);
+    if (lane == 0) {
+        a.energy[r] = e + a.offset;
+        atomicAdd(&a.stats[1], accepted);
+    }
+}
+
+namespace {
+
+
+// Launches the anneal in chunks of at most `resident` replicas (= wavefronts), so that every wave of
+// a launch is co-resident and the sweep pacing rendezvous can complete; chunks run back to back on
+// the stream.  Each chunk gets its own zeroed pacing words.
+template <int NT>
+int launch_dense(const DenseLaunchCtx &p, DenseArgs a, hipStream_t st)
+{
+    if ((*p.resident_waves) == 0) {
+        int blocks_per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_anneal_dense<NT>, 256, 0));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));
+        (*p.resident_waves) = blocks_per_cu * cus * 4;
+        if ((*p.resident_waves) < 4) return fail(MI_EHIP, "anneal kernel cannot be resident (occupancy 0)");
+    }
+    const int total = a.R;
+    const uint32_t base_offset = a.replica_offset;
+    const uint8_t *init0 = a.init;
+    uint8_t *states0 = a.states;
+    double *energy0 = a.energy;
+    int chunk = (*p.resident_waves);
+    if ((total + chunk - 1) / chunk > kMaxChunks) chunk = (total + kMaxChunks - 1) / kMaxChunks;
+    const bool pace = p.opt_pace && a.num_sweeps > 1;
+    if (pace)
+        HIP_TRY(hipMemsetAsync(p.d_pace, 0, kMaxChunks * kPaceWords * sizeof(unsigned int), st));
+    int c = 0;
+    for (int lo = 0; lo < total; lo += chunk, ++c) {
+        const int cnt = total - lo < chunk ? total - lo : chunk;
+        a.R = cnt;
+        a.replica_offset = base_offset + (uint32_t)lo;
+        a.init = init0 ? init0 + (size_t)lo * a.n : nullptr;
+        a.states = states0 + (size_t)lo * a.n;
+        a.energy = energy0 + lo;
+        a.pace = (pace && cnt <= (*p.resident_waves)) ? p.d_pace + (size_t)c * kPaceWords : nullptr;
+        hipLaunchKernelGGL(k_anneal_dense<NT>, dim3((cnt + 3) / 4), dim3(256), 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return MI_OK;
+}
+
+template <int NT, int GR>
+int launch_dense_wg(const DenseLaunchCtx &p, DenseArgs a, hipStream_t st)
+{
+    if constexpr (WgCfg<NT, GR>::ok) {
+        if ((long long)a.num_sweeps * (((a.n + 63) / 64) * (64 / GR)) > 0x7fffffffLL)
+            return fail(MI_EINVAL, "num_sweeps too large for the ring unit counter");
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));
+        const int blocks = (a.R + kWgWaves - 1) / kWgWaves;
+        a.pace = nullptr;
+        if (p.opt_pace && a.num_sweeps > 1 && blocks <= cus) {     // one 160 KB workgroup per CU
+            HIP_TRY(hipMemsetAsync(p.d_pace, 0, kPaceWords * sizeof(unsigned int), st));
+            a.pace = p.d_pace;
+        }
+        hipLaunchKernelGGL((k_anneal_dense_wg<NT, GR>), dim3((a.R + kWgWaves - 1) / kWgWaves), dim3(1024), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    } else {
+        return fail(MI_EUNSUPPORTED, "LDS ring does not fit for NT=%d unit_rows=%d", NT, GR);
+    }
+}
+
+template <int NT>
+int launch_dense_any(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t st)
+{
+    int variant = p.opt_variant;
+    if (variant == 0) variant = (a.R >= 2 * kWgWaves && a.num_sweeps > 0) ? 2 : 1;
+    if (variant == 2) {
+        int gr = p.opt_unit_rows ? p.opt_unit_rows : 4;       // 4 rows per rendezvous measured fastest
+        if (gr == 4 && !WgCfg<NT, 4>::ok) gr = 2;
+        if (gr == 2 && !WgCfg<NT, 2>::ok) gr = 1;
+        switch (gr) {
+            case 2: return launch_dense_wg<NT, 2>(p, a, st);
+            case 4: return launch_dense_wg<NT, 4>(p, a, st);
+        }
+        return fail(MI_EUNSUPPORTED, "LDS ring unit of %d rows is not built for NT=%d", gr, NT);
+    }
+    return launch_dense<NT>(p, a, st);
+}
+
+
+}  // namespace
+
+#define MI_CAT2(a, b) a##b
+#define MI_CAT(a, b) MI_CAT2(a, b)
+int MI_CAT(mi_launch_dense_nt, MI_NT)(const DenseLaunchCtx &ctx, const DenseArgs &a, hipStream_t st)
+{
+    return launch_dense_any<MI_NT>(ctx, a, st);
+}
+
+}  // namespace mi_sa_impl

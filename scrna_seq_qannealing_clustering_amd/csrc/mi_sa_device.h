@@ -1,0 +1,207 @@
+// mi_sa_device.h -- shared device-side pieces of the MI355X annealing engine (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <type_traits>
+
+#include "../../include/mi_sa.h"
+
+namespace mi_sa_impl {
+
+int fail(int code, const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return ::mi_sa_impl::fail(MI_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                                      __FILE__, __LINE__);                                       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device helpers: Philox4x32-10, -ln(u)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t PH_M0 = 0xD2511F53u, PH_M1 = 0xCD9E8D57u;
+constexpr uint32_t PH_W0 = 0x9E3779B9u, PH_W1 = 0xBB67AE85u;
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(PH_M0, c0), lo0 = PH_M0 * c0;
+        const uint32_t hi1 = __umulhi(PH_M1, c2), lo1 = PH_M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += PH_W0; k1 += PH_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// -ln(u), u in (0,1] from the top 23 bits of r; every step one IEEE fp32 op or fma (bit-reproducible).
+__device__ __forceinline__ float neglog_u(uint32_t r)
+{
+    const float mm = __uint_as_float(0x3f800000u | (r >> 9));
+    const float u = 2.0f - mm;
+    const uint32_t ub = __float_as_uint(u);
+    int e = (int)(ub >> 23) - 127;
+    float m = __uint_as_float((ub & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float t = m - 1.0f;
+    float p = -0x1.9f9af6p-4f;
+    p = __fmaf_rn(p, t, 0x1.4cd8dcp-3f);
+    p = __fmaf_rn(p, t, -0x1.61491cp-3f);
+    p = __fmaf_rn(p, t, 0x1.977bcp-3f);
+    p = __fmaf_rn(p, t, -0x1.ff611p-3f);
+    p = __fmaf_rn(p, t, 0x1.555a22p-2f);
+    p = __fmaf_rn(p, t, -0x1.00007cp-1f);
+    p = __fmaf_rn(p, t, 0x1.fffffep-1f);
+    const float lnm = p * t;
+    return __fmaf_rn(-(float)e, 0x1.62e43p-1f, -lnm);
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+
+// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N) -- keeps every f[] index a
+// constant so the field array is register-allocated at any NT (a pragma-unrolled loop falls back to
+// scratch once the body grows past the unroller's budget).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&body)
+{
+    if constexpr (I < N) {
+        body(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(body);
+    }
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sweep pacing (speed only, never correctness)
+// ------------------------------------------------------------------------------------------------
+// Replicas visit the rows of Q in the same order but accept different flips, so they drift apart and
+// their row fetches stop sharing the XCD's 4 MiB L2 (Q is ~30 MB): every fetch then comes from
+// Infinity Cache / HBM.  Holding the replicas of ONE XCD together at each sweep boundary keeps them
+// inside a window of a few hundred rows, which the L2 holds.  No data passes through this rendezvous:
+// results are identical with it on, off, or timing out -- every wait is bounded by a wall-clock
+// limit, so a launch whose waves are not all resident only loses time.
+//   pace[0]            waves started (launch-wide)
+//   pace[1]            pacing disabled (the start rendezvous timed out)
+//   pace[2]            sweep waits that hit their time limit (diagnostic)
+//   pace[32*(1+x)]     waves living on XCD x          (one 128-byte line per XCD)
+//   pace[32*(1+x)+1]   sweep arrivals on XCD x (monotonic)
+constexpr int kPaceWords = 32 * 9;
+constexpr long long kPaceStartTicks = 400000;   // 4 ms of the 100 MHz realtime clock
+constexpr long long kPaceSweepTicks = 200000;   // 2 ms
+
+// wave-uniform read of a pacing word (every lane loads the same address; readfirstlane makes the
+// uniformity visible to the compiler -- a lane-0-only spin loop inside the sweep loop makes hipcc treat
+// the kernel's scalar bookkeeping as divergent and move it to VGPRs)
+__device__ __forceinline__ unsigned int pace_load(const unsigned int *p)
+{
+    return (unsigned int)__builtin_amdgcn_readfirstlane(
+        (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ long long pace_clock()
+{
+    return (long long)__builtin_amdgcn_s_memrealtime();
+}
+
+// returns the XCD population, or 0 when pacing is off for this launch
+__device__ __forceinline__ unsigned int sweep_pace_begin(unsigned int *pace, unsigned int total_waves,
+                                                         unsigned int &xcc)
+{
+    if (!pace) return 0;
+    xcc = (unsigned int)__builtin_amdgcn_readfirstlane(
+              (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) & 7u;   // HW_REG_XCC_ID[3:0]
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&pace[32 * (1 + xcc)], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        atomicAdd(&pace[0], 1u);
+    }
+    const long long t0 = pace_clock();
+    bool ok = true;
+    while (pace_load(&pace[0]) < total_waves) {
+        if (pace_load(&pace[1]) != 0 || pace_clock() - t0 > kPaceStartTicks) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (!ok) {
+        if ((threadIdx.x & 63) == 0)
+            __hip_atomic_store(&pace[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    return pace_load(&pace[32 * (1 + xcc)]);
+}
+
+__device__ __forceinline__ void sweep_pace_arrive_wait(unsigned int *pace, unsigned int xcc,
+                                                       unsigned int pop, unsigned int sweeps_done)
+{
+    unsigned int *arr = &pace[32 * (1 + xcc) + 1];
+    if ((threadIdx.x & 63) == 0) atomicAdd(arr, 1u);
+    const unsigned int target = pop * sweeps_done;
+    const long long t0 = pace_clock();
+    while (pace_load(arr) < target) {
+        if (pace_clock() - t0 > kPaceSweepTicks) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&pace[2], 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: dense binary chain, one wavefront per replica, fields in VGPRs
+// ------------------------------------------------------------------------------------------------
+struct DenseArgs {
+    const float *Qp;        // slot-permuted Q2: row i, float4 index (g*64 + lane) holds columns
+                            // 64*(4g+c)+lane, c = 0..3 ; row stride = NT*64 floats; row n = diagonal
+    const float *temps;     // num_sweeps floats
+    const uint8_t *init;    // nullable, R x n
+    uint8_t *states;        // R x n
+    double *energy;         // R
+    unsigned long long *stats;  // [0] proposals [1] accepted [2] bytes
+    unsigned int *pace;     // sweep pacing words (see sweep_pace_*), zeroed per launch; nullable
+    double offset;
+    int n, R, num_sweeps, resync;
+    uint32_t replica_offset, seed_lo, seed_hi;
+    int debug;              // diagnostic timing builds only: bit0 = skip LDS-DMA, bit1 = accept nothing
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// what a per-NT launcher needs to know about the problem handle
+struct DenseLaunchCtx {
+    int device;
+    int opt_pace, opt_variant, opt_unit_rows;
+    unsigned int *d_pace;          // kMaxChunks * kPaceWords words
+    int *resident_waves;           // cached occupancy of the wave-per-replica kernel (0 = unknown)
+};
+
+constexpr int kMaxChunks = 64;
+
+// one translation unit per NT (dense_kernels.hip compiled with -DMI_NT=<NT>) defines its launcher
+#define MI_DECLARE_DENSE(N) int mi_launch_dense_nt##N(const DenseLaunchCtx &, const DenseArgs &, hipStream_t);
+MI_DECLARE_DENSE(4) MI_DECLARE_DENSE(8) MI_DECLARE_DENSE(12) MI_DECLARE_DENSE(16) MI_DECLARE_DENSE(20)
+MI_DECLARE_DENSE(24) MI_DECLARE_DENSE(28) MI_DECLARE_DENSE(32) MI_DECLARE_DENSE(36) MI_DECLARE_DENSE(40)
+MI_DECLARE_DENSE(44) MI_DECLARE_DENSE(48) MI_DECLARE_DENSE(52) MI_DECLARE_DENSE(56) MI_DECLARE_DENSE(60)
+MI_DECLARE_DENSE(64)
+#undef MI_DECLARE_DENSE
+
+}  // namespace mi_sa_impl

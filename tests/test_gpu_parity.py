@@ -1,7 +1,9 @@
 """Parity of the HIP path against the CPU oracle, through the C ABI (libmi_sa.so).  GPU only.
 
-Bars: binary states / accepted-move counts / integer edge cuts are BIT-EXACT; device energies are
-fp64 sums of fp32 fields, compared at rel 1e-5 (the chain computes in fp32)."""
+Bars: binary states / accepted-move counts / integer edge cuts are BIT-EXACT (the chain computes in
+fp32 with a fully specified operation order); device energies are fp64 sums of the fp32 matrix entries
+and must match the oracle's fp64 re-evaluation to rel 1e-9; against the caller's fp64 coefficients the
+bar is rel 1e-5 (fp32 storage of Q)."""
 import ctypes as C
 
 import numpy as np
@@ -14,7 +16,8 @@ from scrna_seq_qannealing_clustering_amd.engine import Problem
 
 pytestmark = pytest.mark.gpu
 
-E_RTOL = 1e-5
+E_RTOL = 1e-9      # device fp64 energy vs oracle fp64 energy, same fp32 matrix
+E_RTOL_F64Q = 1e-5  # vs energies from the caller's fp64 coefficients
 
 
 def fixture_model(name, gf=0.05):
@@ -45,7 +48,7 @@ def test_trajectory_parity_on_reference_graphs(name):
     ost, oen, ostats = so.sa_dense_philox(Qs, 16, betas, 1234)
     assert np.array_equal(st, ost)                                   # flip for flip
     assert info["accepted"] == int(ostats[1]) and info["proposals"] == int(ostats[0])
-    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-3)
+    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-9)
     assert np.array_equal(so.cut_edges(fx.eu, fx.ev, st), so.cut_edges(fx.eu, fx.ev, ost))
 
 
@@ -57,7 +60,30 @@ def test_trajectory_parity_ragged_sizes(n):
     ost, oen, ostats = so.sa_dense_philox(Qs, 5, betas, 42 + n, offset=1.25)
     assert np.array_equal(st, ost)
     assert info["accepted"] == int(ostats[1])
-    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-3)
+    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("variant,unit_rows", [(1, 0), (2, 2), (2, 4)])
+@pytest.mark.parametrize("n,R", [(1, 3), (64, 16), (65, 37), (300, 33), (1000, 20), (2638, 18)])
+def test_both_kernels_follow_the_same_chain(variant, unit_rows, n, R):
+    """K1 (wave per replica) and K1w (16-replica workgroup, LDS ring; ragged last workgroup) are the same
+    Markov chain: identical states to the oracle for every (size, replica count), with initial states,
+    field re-synchronisation and a replica offset in play."""
+    Qs = random_sym(n, seed=1000 + n)
+    betas = np.geomspace(0.05, 4.0, 9)
+    init = np.random.RandomState(n).randint(0, 2, size=(R, n)).astype(np.uint8)
+    ost, oen, ostats = so.sa_dense_philox(Qs, R, betas, 7, replica_offset=5, init=init, resync_interval=4)
+    with Problem.dense(Qs) as p:
+        p.set_option("variant", variant)
+        p.set_option("unit_rows", unit_rows)
+        p.anneal(R, betas, 7, replica_offset=5, initial_states=init, resync_interval=4)
+        st, en, info = p.fetch()
+        p.set_option("pace", 0)
+        p.anneal(R, betas, 7, replica_offset=5, initial_states=init, resync_interval=4)
+        st2, _, _ = p.fetch()
+    assert np.array_equal(st, ost) and np.array_equal(st2, ost)
+    assert info["accepted"] == int(ostats[1])
+    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-9)
 
 
 def test_initial_states_resync_and_zero_sweeps():
@@ -72,7 +98,7 @@ def test_initial_states_resync_and_zero_sweeps():
     # zero sweeps: the initial states come back, with their energies
     st, en, _ = run_gpu(Qs, 6, betas[:0], 5, initial_states=init)
     assert np.array_equal(st, init)
-    assert np.allclose(en, so.energy_dense_f64(Qs, init), rtol=E_RTOL)
+    assert np.allclose(en, so.energy_dense_f64(Qs, init), rtol=E_RTOL, atol=1e-9)
     # zero sweeps without initial states: the replica's own random initial state
     st, en, _ = run_gpu(Qs, 6, betas[:0], 5)
     ost, _, _ = so.sa_dense_philox(Qs, 6, betas[:0], 5)
@@ -106,7 +132,7 @@ def test_circles_reaches_proven_optimum(kat):
     assert e_best == pytest.approx(kat["noisy_circles"]["comp0_E_closed"], rel=1e-6)
     assert int(so.cut_edges(fx.eu, fx.ev, s_best[None, :])[0]) == 0 and int(s_best.sum()) == 128
     assert m.energies(s_best[None, :])[0] == pytest.approx(-2951.8108596597776, rel=1e-12)
-    assert en.min() <= oen.min() + 1e-3
+    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-9)
     from scrna_seq_qannealing_clustering_amd.distributed import unpack_key
     e32, gid = unpack_key(key)
     assert gid == idx and e32 == pytest.approx(e_best, rel=1e-6)
@@ -188,7 +214,7 @@ def test_full_size_properties_pbmc3k_surrogate():
     assert np.array_equal(st, st2) and np.array_equal(en, en2)                 # deterministic
     assert set(np.unique(st).tolist()) <= {0, 1}
     host = m.energies(st)                                                      # fp64, structured form
-    assert np.allclose(en, host, rtol=E_RTOL)
+    assert np.allclose(en, host, rtol=E_RTOL_F64Q)
     cut = so.cut_edges(eu, ev, st)
     s = st.sum(axis=1).astype(np.float64)
     cut_w = np.array([w[(x[eu] != x[ev])].sum() for x in st])
