@@ -116,6 +116,11 @@ struct mi_sa_problem {
     int NT = 0;
     float *d_Qp = nullptr;
     float *d_Qs = nullptr;       // plain row-major copy (energy kernel), allocated lazily
+    // structured kinds (slot-ELL)
+    int slots = 0, D = 0;
+    float c_pair = 0.0f;
+    uint32_t *d_ell_col = nullptr;
+    float *d_ell_val = nullptr, *d_lin = nullptr;
     // run buffers
     int cap_R = 0, cap_sweeps = 0;
     int last_R = 0;
@@ -266,16 +271,86 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
     return MI_OK;
 }
 
-int mi_sa_problem_create_csr_rank1_f32(const int32_t *, const int32_t *, const float *, const float *,
-                                       float, int, double, int, mi_sa_problem **)
+// CSR (both directions stored) -> slot-ELL device arrays (D = 16 / 32 / 64)
+static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_t *col, const float *val, int n)
 {
-    return fail(MI_EUNSUPPORTED, "csr_rank1 kernel not built yet");
+    int maxdeg = 0;
+    for (int i = 0; i < n; ++i) {
+        const int d = rowptr[i + 1] - rowptr[i];
+        if (d < 0) return fail(MI_EINVAL, "rowptr is not monotone at %d", i);
+        if (d > maxdeg) maxdeg = d;
+    }
+    if (maxdeg > 64)
+        return fail(MI_EUNSUPPORTED, "max degree %d exceeds the slot-ELL width built (64); use the dense kernel", maxdeg);
+    const int D = maxdeg <= 16 ? 16 : (maxdeg <= 32 ? 32 : 64);
+    const int slots = (n + 63) / 64;
+    std::vector<uint32_t> hc((size_t)slots * D * 64);
+    std::vector<float> hv((size_t)slots * D * 64, 0.0f);
+    for (int t = 0; t < slots; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = t * 64 + lane;
+            for (int k = 0; k < D; ++k) hc[((size_t)t * D + k) * 64 + lane] = (uint32_t)(i < n ? i : 0);
+            if (i >= n) continue;
+            for (int e = rowptr[i], k = 0; e < rowptr[i + 1]; ++e, ++k) {
+                if (col[e] < 0 || col[e] >= n || col[e] == i)
+                    return fail(MI_EINVAL, "bad column %d in row %d", col[e], i);
+                hc[((size_t)t * D + k) * 64 + lane] = (uint32_t)col[e];
+                hv[((size_t)t * D + k) * 64 + lane] = val[e];
+            }
+        }
+    HIP_TRY(hipMalloc((void **)&p->d_ell_col, hc.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&p->d_ell_val, hv.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(p->d_ell_col, hc.data(), hc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_ell_val, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+    p->slots = slots;
+    p->D = D;
+    return MI_OK;
 }
 
-int mi_sa_problem_create_potts_csr_f32(const int32_t *, const int32_t *, const float *, float, int, int,
-                                       double, int, mi_sa_problem **)
+int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                                       const float *lin, float c_pair, int n, double offset, int device,
+                                       mi_sa_problem **out)
 {
-    return fail(MI_EUNSUPPORTED, "potts kernel not built yet");
+    if (!rowptr || !lin || !out || (rowptr[n > 0 ? n : 0] > 0 && (!col || !val))) return fail(MI_EINVAL, "NULL argument");
+    if (n < 1) return fail(MI_EINVAL, "n must be >= 1 (got %d)", n);
+    if (n > 4096) return fail(MI_EUNSUPPORTED, "csr_rank1 kernel supports n <= 4096 (got %d)", n);
+    int rc = select_device(device);
+    if (rc) return rc;
+    mi_sa_problem *p = new (std::nothrow) mi_sa_problem();
+    if (!p) return fail(MI_ENOMEM, "out of host memory");
+    p->kind = MI_KIND_CSR_RANK1; p->n = n; p->K = 2; p->offset = offset; p->state_elem = 1; p->c_pair = c_pair;
+    rc = problem_common_init(p, device);
+    if (!rc) rc = upload_slot_ell(p, rowptr, col, val, n);
+    if (!rc) rc = [&]() -> int {
+        std::vector<float> hl((size_t)p->slots * 64, 0.0f);
+        for (int i = 0; i < n; ++i) hl[i] = lin[i];
+        HIP_TRY(hipMalloc((void **)&p->d_lin, hl.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(p->d_lin, hl.data(), hl.size() * sizeof(float), hipMemcpyHostToDevice));
+        return MI_OK;
+    }();
+    if (rc) { mi_sa_problem_destroy(p); return rc; }
+    *out = p;
+    return MI_OK;
+}
+
+int mi_sa_problem_create_potts_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                                       float c_pair, int n, int K, double lin_offset, int device,
+                                       mi_sa_problem **out)
+{
+    if (!rowptr || !out || (rowptr[n > 0 ? n : 0] > 0 && (!col || !val))) return fail(MI_EINVAL, "NULL argument");
+    if (n < 1) return fail(MI_EINVAL, "n must be >= 1 (got %d)", n);
+    if (K < 1 || K > 64) return fail(MI_EUNSUPPORTED, "potts kernel supports 1 <= K <= 64 cases (got %d)", K);
+    if (n > 40000) return fail(MI_EUNSUPPORTED, "potts kernel supports n <= 40000 (got %d)", n);
+    int rc = select_device(device);
+    if (rc) return rc;
+    mi_sa_problem *p = new (std::nothrow) mi_sa_problem();
+    if (!p) return fail(MI_ENOMEM, "out of host memory");
+    p->kind = MI_KIND_POTTS_CSR; p->n = n; p->K = K; p->offset = lin_offset; p->state_elem = 2; p->c_pair = c_pair;
+    rc = problem_common_init(p, device);
+    if (!rc) rc = upload_slot_ell(p, rowptr, col, val, n);
+    if (rc) { mi_sa_problem_destroy(p); return rc; }
+    *out = p;
+    return MI_OK;
 }
 
 int mi_sa_problem_destroy(mi_sa_problem *p)
@@ -283,7 +358,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -359,7 +434,22 @@ int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweep
         if (rc) return rc;
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
     } else {
-        return fail(MI_EUNSUPPORTED, "kind %d not built yet", p->kind);
+        EllArgs a;
+        a.ell_col = p->d_ell_col; a.ell_val = p->d_ell_val; a.lin = p->d_lin; a.temps = p->d_temps;
+        a.init = init ? p->d_init : nullptr; a.states = p->d_states; a.energy = p->d_energy; a.stats = p->d_stats;
+        a.c_pair = p->c_pair; a.offset = p->offset; a.n = p->n; a.K = p->K; a.R = R; a.num_sweeps = num_sweeps;
+        a.resync = resync_interval; a.slots = p->slots; a.D = p->D;
+        a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+        if (p->kind == MI_KIND_POTTS_CSR && init) {
+            // labels must be < K: validated on the host copy (the device trusts them as cnt[] indices)
+            const uint16_t *l = static_cast<const uint16_t *>(init);
+            for (size_t k = 0; k < (size_t)R * p->n; ++k)
+                if (l[k] >= (uint16_t)p->K) return fail(MI_EINVAL, "initial label %u >= K = %d", (unsigned)l[k], p->K);
+        }
+        HIP_TRY(hipEventRecord(p->ev0, p->stream));
+        rc = (p->kind == MI_KIND_POTTS_CSR) ? mi_launch_potts(a, p->stream) : mi_launch_csr_rank1(a, p->stream);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(p->ev1, p->stream));
     }
     p->last_R = R; p->last_offset = replica_offset; p->has_run = true;
     return MI_OK;

@@ -186,6 +186,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// arguments of the structured (slot-ELL) kernels K2 / K3 -- sparse_kernels.hip
+struct EllArgs {
+    const uint32_t *ell_col;   // [slots][D][64] neighbour indices (padding: the variable itself)
+    const float *ell_val;      // [slots][D][64] S_ij            (padding: +0.0f)
+    const float *lin;          // K2: slots*64 linear terms (zero padded); K3: unused
+    const float *temps;        // num_sweeps
+    const void *init;          // nullable: R x n uint8 (K2) / uint16 (K3)
+    void *states;              // R x n uint8 (K2) / uint16 (K3)
+    double *energy;            // R
+    unsigned long long *stats; // [1] accepted
+    float c_pair;
+    double offset;             // K2: offset; K3: lin_offset
+    int n, K, R, num_sweeps, resync, slots, D;
+    uint32_t replica_offset, seed_lo, seed_hi;
+};
+int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
+int mi_launch_potts(const EllArgs &, hipStream_t);
+
 // what a per-NT launcher needs to know about the problem handle
 struct DenseLaunchCtx {
     int device;

@@ -1,0 +1,163 @@
+"""Parity of the structured kernels (K2: CSR + uniform pair term, K3: Potts / DQM) against the oracle,
+through the C ABI.  GPU only.  States / labels / accepted-move counts / edge cuts are bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import GRAPH_NAMES, load_fixture
+from oracle import model_oracle as mo
+from oracle import sa_oracle as so
+from scrna_seq_qannealing_clustering_amd import MI355XSampler, _lib, models
+from scrna_seq_qannealing_clustering_amd.bqm import DiscreteQuadraticModel
+from scrna_seq_qannealing_clustering_amd.engine import Problem
+
+pytestmark = pytest.mark.gpu
+
+
+def f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+@pytest.mark.parametrize("name", GRAPH_NAMES)
+def test_csr_rank1_trajectory_parity(name):
+    fx = load_fixture(name)
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    betas = models.make_beta_schedule(40, models.default_beta_range(m))
+    args = (m.rowptr, m.col, f32(m.val), f32(m.lin), float(np.float32(m.c_pair)))
+    init = np.random.RandomState(2).randint(0, 2, size=(9, 256)).astype(np.uint8)
+    for kw in (dict(), dict(init=init, resync_interval=5)):
+        ost, oen, ostats = so.sa_csr_rank1_philox(*args, 9, betas, 1234, replica_offset=3, **kw)
+        with Problem.csr_rank1(*args) as p:
+            p.anneal(9, betas, 1234, replica_offset=3, initial_states=kw.get("init"),
+                     resync_interval=kw.get("resync_interval", 0))
+            st, en, info = p.fetch()
+            idx, e_best, key, s_best = p.best()
+        assert np.array_equal(st, ost)
+        assert info["accepted"] == int(ostats[1])
+        assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+        assert np.array_equal(so.cut_edges(fx.eu, fx.ev, st), so.cut_edges(fx.eu, fx.ev, ost))
+        assert en[idx] == en.min() and np.array_equal(s_best, st[idx])
+        # same model as the dense form: energies agree with the fp64 coefficients
+        assert np.allclose(en, m.energies(st), rtol=1e-5)
+
+
+def test_csr_rank1_reaches_circles_optimum(kat):
+    fx = load_fixture("noisy_circles")
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    betas = models.make_beta_schedule(1000, models.default_beta_range(m))
+    with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), float(np.float32(m.c_pair))) as p:
+        p.anneal(64, betas, 1234)
+        st, en, _ = p.fetch()
+    best = st[int(np.argmin(en))]
+    assert m.energies(best[None, :])[0] == pytest.approx(kat["noisy_circles"]["comp0_E_closed"], rel=1e-12)
+    assert int(so.cut_edges(fx.eu, fx.ev, best[None, :])[0]) == 0
+
+
+def test_csr_rank1_sparse_only_model_and_ragged_n():
+    """A2-shaped model (no uniform pair term) on an induced subgraph with n not a multiple of 64."""
+    fx = load_fixture("varied")
+    keep = fx.nodes[:150]
+    G = fx.graph().subgraph(keep)
+    m = models.build_bqm2_qubo(G, 0.01, 1)
+    assert m.c_pair == 0.0 and m.num_variables == 150
+    betas = np.geomspace(0.1, 20.0, 25)
+    args = (m.rowptr, m.col, f32(m.val), f32(m.lin), 0.0)
+    ost, oen, ostats = so.sa_csr_rank1_philox(*args, 5, betas, 9)
+    with Problem.csr_rank1(*args) as p:
+        p.anneal(5, betas, 9)
+        st, en, info = p.fetch()
+    assert np.array_equal(st, ost) and info["accepted"] == int(ostats[1])
+    assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,K", [("noisy_circles", 3), ("blobs", 3), ("aniso", 8), ("no_structure", 15)])
+def test_potts_trajectory_parity(name, K):
+    fx = load_fixture(name)
+    pm = models.build_dqm_potts(fx.graph(), K, 0.005)
+    from scrna_seq_qannealing_clustering_amd.sampler import default_potts_beta_range
+    betas = models.make_beta_schedule(40, default_potts_beta_range(pm))
+    args = (pm.rowptr, pm.col, f32(pm.val), float(np.float32(pm.c_pair)), 256, K)
+    init = np.random.RandomState(4).randint(0, K, size=(7, 256)).astype(np.uint16)
+    for kw in (dict(), dict(init=init)):
+        olab, oen, ostats = so.potts_csr_philox(*args, 7, betas, 77, lin_offset=pm.lin_offset,
+                                                replica_offset=11, **kw)
+        with Problem.potts_csr(*args, lin_offset=pm.lin_offset) as p:
+            p.anneal(7, betas, 77, replica_offset=11, initial_states=kw.get("init"))
+            lab, en, info = p.fetch()
+        assert lab.dtype == np.uint16 and np.array_equal(lab, olab)
+        assert info["accepted"] == int(ostats[1])
+        assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+        assert np.allclose(en, pm.energies(lab), rtol=1e-5)
+        assert np.array_equal(so.cut_edges(fx.eu, fx.ev, lab), so.cut_edges(fx.eu, fx.ev, olab))
+
+
+def test_sample_dqm_like_clustering_dqm(kat):
+    """DQM_clustering.py:29-47 on the reference's circles graph: K = 3, gamma = 0.005."""
+    fx = load_fixture("noisy_circles")
+    pm = models.build_dqm_potts(fx.graph(), 3, 0.005)
+    sampler = MI355XSampler()
+    ss = sampler.sample_dqm(pm, label="DQM - scRAN-seq", num_reads=64, num_sweeps=500, seed=5)
+    assert ss.vartype == "DISCRETE"
+    lut = ss.first.sample
+    assert list(lut.keys()) == fx.nodes                      # variable order = G.nodes order
+    lab = np.array(list(lut.values()))
+    # literal reference model evaluates the returned labels to the returned energy
+    lin, quad = mo.dqm_model(fx.nodes, fx.edges, 3, 0.005)
+    assert ss.first.energy == pytest.approx(mo.dqm_energy(lin, quad, dict(lut)), rel=1e-10)
+    # integer edge cut of the best labelling, recomputed two ways
+    assert int(so.cut_edges(fx.eu, fx.ev, lab[None, :].astype(np.uint16))[0]) == mo.cut_edges(fx.edges, dict(lut))
+    # P3: the same best energy as the CPU oracle's chain at equal (reads, sweeps, schedule, seed), and far
+    # below a random labelling (the known labels-=-components value is kat["dqm_circles"]; single-site
+    # Potts moves at 500 sweeps do not always merge the domains, on the oracle either)
+    betas = models.make_beta_schedule(500, ss.info["beta_range"])
+    olab, oen, _ = so.potts_csr_philox(pm.rowptr, pm.col, f32(pm.val), float(np.float32(pm.c_pair)), 256, 3,
+                                       64, betas, 5, lin_offset=pm.lin_offset)
+    assert pm.energies(olab).min() == pytest.approx(ss.first.energy, rel=1e-12)
+    rnd = np.random.RandomState(0).randint(0, 3, size=(16, 256))
+    assert ss.first.energy < pm.energies(rnd).min() - 100.0
+    assert ss.first.energy < kat["dqm_circles"]["E_pairwise"] + 60.0
+    assert ss.info["kernel"] == "potts_csr"
+
+
+def test_dqm_lookalike_through_sampler():
+    fx = load_fixture("noisy_moons")
+    keep = fx.nodes[:40]
+    ks = set(keep)
+    edges = [(u, v, w) for u, v, w in fx.edges if u in ks and v in ks]
+    from itertools import combinations
+    K, gamma = 3, 0.05
+    dqm = DiscreteQuadraticModel()
+    for node in keep:
+        dqm.add_variable(K, label=node)
+    for node in keep:
+        dqm.set_linear(node, [gamma * (1 - len(keep) / K)] * K)
+    for i, j in combinations(keep, 2):
+        dqm.set_quadratic(i, j, {(c, c): 2 * gamma for c in range(K)})
+    for u, v, w in edges:
+        dqm.set_quadratic(u, v, {(c, c): -2 * w for c in range(K)})
+        dqm.set_linear(u, [w] * K)
+        dqm.set_linear(v, [w] * K)
+    ss = MI355XSampler().sample_dqm(dqm, num_reads=32, num_sweeps=300, seed=1)
+    assert ss.first.energy == pytest.approx(dqm.energy(dict(ss.first.sample)), rel=1e-10)
+    assert len(set(ss.first.sample.values())) >= 1
+
+
+def test_structured_error_behaviour():
+    rowptr = np.array([0, 1, 2], dtype=np.int32)
+    col = np.array([1, 0], dtype=np.int32)
+    val = np.array([1.0, 1.0], dtype=np.float32)
+    with pytest.raises(_lib.MiSaError) as ei:
+        Problem.potts_csr(rowptr, col, val, 0.0, 2, 65)           # K too large
+    assert ei.value.code == -5
+    with pytest.raises(_lib.MiSaError):
+        Problem.potts_csr(rowptr, np.array([5, 0], dtype=np.int32), val, 0.0, 2, 3)   # bad column
+    p = Problem.potts_csr(rowptr, col, val, 0.0, 2, 3)
+    with pytest.raises(_lib.MiSaError):
+        p.anneal(1, [1.0], 1, initial_states=np.array([[0, 7]], dtype=np.uint16))      # label >= K
+    p.close()
+    # degree > 32 is outside the slot-ELL width
+    n = 40
+    rp = np.arange(0, n * (n - 1) + 1, n - 1, dtype=np.int32)
+    cc = np.array([j for i in range(n) for j in range(n) if j != i], dtype=np.int32)
+    with pytest.raises(_lib.MiSaError) as ei:
+        Problem.csr_rank1(rp, cc, np.ones(len(cc), dtype=np.float32), np.zeros(n, dtype=np.float32), 0.0)
+    assert ei.value.code == -5
