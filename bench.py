@@ -40,7 +40,7 @@ def build_workload():
     m = models.build_bqm_qubo(G, 0.05, k=8)
     Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))
     betas = models.make_beta_schedule(SWEEPS, models.default_beta_range(m))
-    return m, Qs, betas, (eu, ev, w)
+    return m, Qs, betas, (eu, ev, w), G
 
 
 def cpu_baseline(Qs, betas, seconds_target=15.0):
@@ -72,6 +72,52 @@ def cpu_baseline(Qs, betas, seconds_target=15.0):
     }
 
 
+def pmc_traffic(replicas, sweeps):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload
+    (profiles/r01_pmc_traffic.json, written by scripts/pmc_traffic.py on the GPU box: FETCH_SIZE doubled
+    per the gfx950 note + WRITE_SIZE).  None when no profile matches this launch shape."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get("replicas") == replicas and rec.get("sweeps") == sweeps:
+        return float(rec["hbm_bytes_per_launch"])
+    return None
+
+
+def other_kernels(m, betas, graph, rank_device):
+    """Short untimed-region runs of the structured kernels on the same graph (reported beside the headline,
+    never part of `value`): K2 = the same QUBO in CSR + uniform-pair form, K3 = BASELINE config 3 (DQM K=8)."""
+    from scrna_seq_qannealing_clustering_amd import models
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    from scrna_seq_qannealing_clustering_amd.sampler import default_potts_beta_range
+    out = {}
+    n = m.num_variables
+    R, S = REPLICAS_PER_GPU, 200
+    with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
+                           float(np.float32(m.c_pair)), device=rank_device) as p:
+        b = models.make_beta_schedule(S, models.default_beta_range(m))
+        p.anneal(R, b, SEED)
+        ms = p.kernel_ms()
+        st, en, info = p.fetch()
+        out["csr_rank1_bqm"] = {"kernel": "k_anneal_csr_rank1<16>", "replicas": R, "sweeps": S, "kernel_ms": ms,
+                                "updates_per_s": R * S * n / (ms * 1e-3),
+                                "best_energy": float(m.energies(st[int(np.argmin(en))][None, :])[0]),
+                                "acceptance": info["accepted"] / info["proposals"]}
+    pm = models.build_dqm_potts(graph, 8, 0.005)
+    with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(np.float32), float(np.float32(pm.c_pair)), n, 8,
+                           lin_offset=pm.lin_offset, device=rank_device) as p:
+        b = models.make_beta_schedule(S, default_potts_beta_range(pm))
+        p.anneal(R, b, SEED)
+        ms = p.kernel_ms()
+        lab, en, info = p.fetch()
+        out["potts_dqm_k8"] = {"kernel": "k_anneal_potts<16>", "replicas": R, "sweeps": S, "kernel_ms": ms,
+                               "updates_per_s": R * S * n / (ms * 1e-3), "best_energy": float(en.min()),
+                               "acceptance": info["accepted"] / info["proposals"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,7 +140,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local)
 
-    m, Qs, betas, (eu, ev, w) = build_workload()
+    m, Qs, betas, (eu, ev, w), graph = build_workload()
     if args.sweeps != SWEEPS:
         from scrna_seq_qannealing_clustering_amd import models
         betas = models.make_beta_schedule(args.sweeps, models.default_beta_range(m))
@@ -148,8 +194,8 @@ def main():
                                "geometric beta, seed 1234" % (R, len(betas)),
                    "n": n, "replicas_per_gpu": R, "sweeps": int(len(betas)), "parallelism": "replicas sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "k_anneal_dense<44>", "kernel_ms": k_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(R, len(betas)),
+                     "kernel": "k_anneal_dense_wg<44,4>", "kernel_ms": k_ms,
                      "algorithmic_bytes_per_update": 4 * n,
                      "rows_GBps": row_bytes / (k_ms * 1e-3) / 1e9,
                      "acceptance": info["accepted"] / info["proposals"]},
@@ -160,6 +206,7 @@ def main():
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
+            out["other_kernels"] = other_kernels(m, betas, graph, local)
             out["cpu_baseline"] = cpu_baseline(Qs, betas)
         else:
             out["cpu_baseline"] = None

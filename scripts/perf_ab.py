@@ -19,7 +19,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("arms", nargs="*", default=["pace=0", "pace=1"])
 a = ap.parse_args()
-m, Qs, betas_full, _ = bench.build_workload()
+m, Qs, betas_full, _, _graph = bench.build_workload()
 betas = models.make_beta_schedule(a.sweeps, models.default_beta_range(m))
 n = Qs.shape[0]
 ref = None

@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 passes over the bench workload itself (1 step): kernel trace + stats, then FETCH_SIZE and
+# WRITE_SIZE in their own --pmc passes (never combined with trace domains).
+set -u
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/trace.log 2>&1
+for f in $(find $out/trace -name '*kernel_stats.csv'); do cp $f $out/kernel_stats.csv; done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/$c.log 2>&1
+  for f in $(find $out/$c -name '*counter_collection.csv'); do head -1 $f > $out/$c.csv; grep anneal $f >> $out/$c.csv; done
+  rm -rf $out/$c
+done
+rm -rf $out/trace
+ls -la $out; cat $out/kernel_stats.csv
