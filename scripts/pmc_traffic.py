@@ -5,7 +5,7 @@ half of a wide coalesced stream -- MI355X_MICROARCH.md section HBM -- so it is d
 import csv, glob, json, os, sys
 d = sys.argv[1]
 vals = {}
-for f in glob.glob(os.path.join(d, "*.csv")):
+for f in glob.glob(os.path.join(d, "*_SIZE.csv")):
     for r in csv.DictReader(open(f)):
         if "anneal" in r["Kernel_Name"]:
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
