@@ -52,6 +52,8 @@ def _declare(lib):
         "mi_sa_qubo_dense_f32": (C.c_int, [f32p, C.c_int, C.c_double, C.c_int, C.c_int, f64p,
                                            C.c_uint64, u8p, u8p, f64p, u64p, C.c_int]),
         "mi_energy_dense_f32": (C.c_int, [f32p, C.c_int, u8p, C.c_int, C.c_double, f64p, C.c_int]),
+        "mi_energy_dense_f32_ex": (C.c_int, [f32p, C.c_int, u8p, C.c_int, C.c_double, f64p, C.c_int, C.c_int,
+                                             f32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
@@ -65,7 +67,7 @@ EXPORTS = (
     "mi_sa_problem_create_dense_f32", "mi_sa_problem_create_csr_rank1_f32",
     "mi_sa_problem_create_potts_csr_f32", "mi_sa_problem_destroy", "mi_sa_problem_info",
     "mi_sa_set_option", "mi_sa_debug_pace", "mi_sa_anneal", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_fetch", "mi_sa_best",
-    "mi_sa_qubo_dense_f32", "mi_energy_dense_f32",
+    "mi_sa_qubo_dense_f32", "mi_energy_dense_f32", "mi_energy_dense_f32_ex",
 )
 
 

@@ -50,30 +50,6 @@ int fail(int code, const char *fmt, ...)
 
 
 // ------------------------------------------------------------------------------------------------
-// K4 (VALU form): energies of arbitrary states, one wavefront per state
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_energy_dense_valu(const float *__restrict__ Qs, int n,
-                                                           const uint8_t *__restrict__ X, int R,
-                                                           double offset, double *__restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
-    const uint8_t *x = X + (size_t)r * n;
-    double e = 0.0;
-    for (int i = 0; i < n; ++i) {
-        if (!x[i]) continue;                    // wave-uniform (same address for all lanes)
-        const float *row = Qs + (size_t)i * n;
-        float acc = 0.0f;
-        for (int j = lane; j < n; j += 64)
-            if (x[j]) acc += row[j];
-        e += (double)acc;
-    }
-    e = wave_sum_f64(e);
-    if (lane == 0) out[r] = e + offset;
-}
-
-// ------------------------------------------------------------------------------------------------
 // K5: best-of-replicas: packed (sortable(float E) << 32 | global id) minimum
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t sortable_f32(float v)
@@ -528,30 +504,49 @@ int mi_sa_qubo_dense_f32(const float *Qs, int n, double offset, int R, int num_s
     return rc;
 }
 
-int mi_energy_dense_f32(const float *Qs, int n, const uint8_t *X, int R, double offset,
-                        double *out_energy, int device)
+int mi_energy_dense_f32_ex(const float *Qs, int n, const uint8_t *X, int R, double offset,
+                           double *out_energy, int device, int path, float *out_kernel_ms)
 {
     if (!Qs || !X || !out_energy) return fail(MI_EINVAL, "NULL argument");
     if (n < 1 || R < 1) return fail(MI_EINVAL, "n and R must be >= 1");
+    if (path < 0 || path > 2) return fail(MI_EINVAL, "path must be 0 (auto), 1 (VALU) or 2 (MFMA)");
+    if (path == 0) path = (R >= 32) ? 2 : 1;      // MFMA only when the batch is a real dense contraction
     int rc = select_device(device);
     if (rc) return rc;
-    float *dQ = nullptr; uint8_t *dX = nullptr; double *dE = nullptr;
+    float *dQ = nullptr; uint8_t *dX = nullptr, *dXt = nullptr; double *dE = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     rc = [&]() -> int {
+        const size_t Rpad = ((size_t)R + 63) / 64 * 64;
         HIP_TRY(hipMalloc((void **)&dQ, (size_t)n * n * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&dX, (size_t)R * n));
         HIP_TRY(hipMalloc((void **)&dE, (size_t)R * sizeof(double)));
+        if (path == 2) HIP_TRY(hipMalloc((void **)&dXt, (size_t)n * Rpad));
         HIP_TRY(hipMemcpy(dQ, Qs, (size_t)n * n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dX, X, (size_t)R * n, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_energy_dense_valu, dim3((R + 3) / 4), dim3(256), 0, 0, dQ, n, dX, R, offset, dE);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, 0));
+        int r2 = mi_launch_energy_dense(dQ, n, dX, R, offset, dE, dXt, path, 0);
+        if (r2) return r2;
+        HIP_TRY(hipEventRecord(e1, 0));
+        HIP_TRY(hipEventSynchronize(e1));
+        if (out_kernel_ms) HIP_TRY(hipEventElapsedTime(out_kernel_ms, e0, e1));
         HIP_TRY(hipMemcpy(out_energy, dE, (size_t)R * sizeof(double), hipMemcpyDeviceToHost));
         return MI_OK;
     }();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     if (dQ) (void)hipFree(dQ);
     if (dX) (void)hipFree(dX);
+    if (dXt) (void)hipFree(dXt);
     if (dE) (void)hipFree(dE);
     return rc;
+}
+
+int mi_energy_dense_f32(const float *Qs, int n, const uint8_t *X, int R, double offset,
+                        double *out_energy, int device)
+{
+    return mi_energy_dense_f32_ex(Qs, n, X, R, offset, out_energy, device, 0, nullptr);
 }
 
 }  // extern "C"

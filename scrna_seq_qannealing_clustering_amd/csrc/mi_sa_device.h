@@ -204,6 +204,10 @@ struct EllArgs {
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_potts(const EllArgs &, hipStream_t);
 
+// K4 launcher (energy_kernels.hip); all pointers are device pointers
+int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, double offset, double *dE,
+                           uint8_t *dXt, int path, hipStream_t st);
+
 // what a per-NT launcher needs to know about the problem handle
 struct DenseLaunchCtx {
     int device;

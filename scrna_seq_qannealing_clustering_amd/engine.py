@@ -146,14 +146,17 @@ class Problem:
         return int(idx.value), float(en.value), int(key.value), st
 
 
-def energy_dense(Qs: np.ndarray, X: np.ndarray, offset: float = 0.0, device: int = 0) -> np.ndarray:
-    """Batched ``E_r = x_r^T Qs x_r + offset`` on the GPU (kernel K4)."""
+def energy_dense(Qs: np.ndarray, X: np.ndarray, offset: float = 0.0, device: int = 0, path: int = 0,
+                 return_ms: bool = False):
+    """Batched ``E_r = x_r^T Qs x_r + offset`` on the GPU (kernel K4).  ``path``: 0 auto (MFMA for
+    batches of >= 32 states), 1 exact-fp64 VALU, 2 f32-input MFMA."""
     Qs = np.ascontiguousarray(Qs, dtype=np.float32)
     X = np.ascontiguousarray(X, dtype=np.uint8)
     if X.ndim != 2 or X.shape[1] != Qs.shape[0]:
         raise ValueError("X must have shape (R, n)")
     out = np.empty(X.shape[0], dtype=np.float64)
-    _lib.check(_lib.load().mi_energy_dense_f32(_ptr(Qs, C.c_float), Qs.shape[0], _ptr(X, C.c_uint8),
-                                               X.shape[0], float(offset), _ptr(out, C.c_double),
-                                               int(device)))
-    return out
+    ms = C.c_float(0.0)
+    _lib.check(_lib.load().mi_energy_dense_f32_ex(_ptr(Qs, C.c_float), Qs.shape[0], _ptr(X, C.c_uint8),
+                                                  X.shape[0], float(offset), _ptr(out, C.c_double),
+                                                  int(device), int(path), C.byref(ms)))
+    return (out, float(ms.value)) if return_ms else out

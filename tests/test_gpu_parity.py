@@ -139,20 +139,57 @@ def test_circles_reaches_proven_optimum(kat):
 
 
 def test_energy_kernel_parity():
+    """K4, both forms: exact-fp64 VALU (rel 1e-12) and the f32-input MFMA contraction (rel 1e-6, stated in
+    include/mi_sa.h: fp32 partial sums of <= 32 terms folded into fp64)."""
     fx, m, Qs = fixture_model("aniso")
     rng = np.random.RandomState(3)
     X = rng.randint(0, 2, size=(37, 256)).astype(np.uint8)
     X[0] = 0
     X[1] = 1
-    got = engine.energy_dense(Qs, X, offset=-2.0)
     want = so.energy_dense_f64(Qs, X, offset=-2.0)
-    assert np.allclose(got, want, rtol=1e-6, atol=1e-4)
-    assert got[0] == -2.0
-    # Z2 symmetry of the balanced-partition model: E(x) == E(1 - x)
-    assert np.allclose(engine.energy_dense(Qs, 1 - X), engine.energy_dense(Qs, X), rtol=1e-6, atol=2e-3)
-    Qr = random_sym(130, 8)
-    Xr = rng.randint(0, 2, size=(3, 130)).astype(np.uint8)
-    assert np.allclose(engine.energy_dense(Qr, Xr), so.energy_dense_f64(Qr, Xr), rtol=1e-6, atol=1e-4)
+    got_valu = engine.energy_dense(Qs, X, offset=-2.0, path=1)
+    got_mfma = engine.energy_dense(Qs, X, offset=-2.0, path=2)
+    got_auto = engine.energy_dense(Qs, X, offset=-2.0)
+    assert np.allclose(got_valu, want, rtol=1e-12, atol=1e-9)
+    assert np.allclose(got_mfma, want, rtol=1e-6, atol=1e-3)
+    assert np.array_equal(got_auto, got_mfma) or np.allclose(got_auto, got_mfma, rtol=1e-12)   # R >= 32 -> MFMA
+    assert got_valu[0] == -2.0 and got_mfma[0] == -2.0
+    # Z2 symmetry of the balanced-partition model, E(x) == E(1 - x), up to the fp32 rounding of Q
+    assert np.allclose(engine.energy_dense(Qs, 1 - X, path=1), engine.energy_dense(Qs, X, path=1), rtol=1e-6, atol=2e-3)
+
+
+@pytest.mark.parametrize("n,R", [(1, 1), (2, 33), (31, 64), (33, 65), (130, 3), (257, 100), (1000, 130)])
+def test_energy_kernel_ragged_shapes(n, R):
+    """A = I-style check with an ASYMMETRIC-looking operand: random symmetric Q, random states, every
+    tile edge (n, R not multiples of 32 / 64) exercised on the MFMA path."""
+    Qr = random_sym(n, 8 + n)
+    Xr = np.random.RandomState(R).randint(0, 2, size=(R, n)).astype(np.uint8)
+    want = so.energy_dense_f64(Qr, Xr, offset=0.5)
+    assert np.allclose(engine.energy_dense(Qr, Xr, offset=0.5, path=1), want, rtol=1e-12, atol=1e-9)
+    scale = np.abs(Qr).sum() if n > 1 else 1.0
+    assert np.allclose(engine.energy_dense(Qr, Xr, offset=0.5, path=2), want, rtol=1e-6, atol=1e-6 * scale / max(n, 1))
+    # single-entry operands: E must pick exactly Q[i][j] + Q[j][i] + Q[i][i] + Q[j][j]
+    if n >= 3:
+        Xe = np.zeros((32, n), dtype=np.uint8)
+        for r in range(32):
+            Xe[r, r % n] = 1
+            Xe[r, (3 * r + 1) % n] = 1
+        assert np.allclose(engine.energy_dense(Qr, Xe, path=2), so.energy_dense_f64(Qr, Xe), rtol=1e-6, atol=1e-6)
+
+
+def test_energy_mfma_full_size_batch():
+    """BASELINE config 2 shape: 4096 states x n = 2638 on the matrix cores vs the exact VALU form."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(2638, 5, 15, 15, 9, seed=0)
+    m = models.build_bqm_qubo(graphs.EdgeListGraph(nodes, eu, ev, w), 0.05)
+    Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))
+    X = np.random.RandomState(0).randint(0, 2, size=(4096, 2638)).astype(np.uint8)
+    e_mfma, ms_mfma = engine.energy_dense(Qs, X, path=2, return_ms=True)
+    e_valu, ms_valu = engine.energy_dense(Qs[:, :], X[:128], path=1, return_ms=True)
+    assert np.allclose(e_mfma[:128], e_valu, rtol=2e-6)
+    assert np.allclose(e_mfma, m.energies(X), rtol=1e-5)
+    flops = 2.0 * 2638 * 2638 * 4096
+    print("K4 MFMA: %.3f ms for 4096 x 2638 (%.1f TFLOP/s f32)" % (ms_mfma, flops / ms_mfma / 1e9))
 
 
 def test_one_shot_c_entry_point():
