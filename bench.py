@@ -205,8 +205,9 @@ def main():
         "energy_lower_bound": float(-m.info["gamma"] * n * n / 4),
     }
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if world == 1:
             out["other_kernels"] = other_kernels(m, betas, graph, local)
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(Qs, betas)
         else:
             out["cpu_baseline"] = None

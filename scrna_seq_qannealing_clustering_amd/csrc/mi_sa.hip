@@ -289,7 +289,7 @@ int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col
 {
     if (!rowptr || !lin || !out || (rowptr[n > 0 ? n : 0] > 0 && (!col || !val))) return fail(MI_EINVAL, "NULL argument");
     if (n < 1) return fail(MI_EINVAL, "n must be >= 1 (got %d)", n);
-    if (n > 4096) return fail(MI_EUNSUPPORTED, "csr_rank1 kernel supports n <= 4096 (got %d)", n);
+    if (n > 16384) return fail(MI_EUNSUPPORTED, "csr_rank1 kernel supports n <= 16384 (got %d)", n);
     int rc = select_device(device);
     if (rc) return rc;
     mi_sa_problem *p = new (std::nothrow) mi_sa_problem();

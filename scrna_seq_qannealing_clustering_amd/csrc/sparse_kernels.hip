@@ -32,7 +32,14 @@ __device__ __forceinline__ void slot_words(uint32_t (&w)[4], int tg, int lane, u
 // K2
 // ------------------------------------------------------------------------------------------------
 // LDS per wave: g[slots*64] floats (cached g_i = lin_i + sum_j S_ij x_j), then 2*D words of scratch
-// through which the committing lane hands its adjacency row to lanes 0..D-1.
+// through which the committing lane hands its adjacency row to lanes 0..D-1:
+//   committing lane: 2D ds_write_b32;  lane k < D: reads its (col, val), then g[col] += sgn*val (one IEEE
+//   fp32 add, the oracle's rounding).  (Measured: ds_write_b128 + ds_add_f32 in place of this was 15 % SLOWER.)
+// At D = 16 a flip costs about as many instructions here as a whole dense row update in K1w, so K2's role
+// is the sizes the dense kernels cannot hold (n > 4096), not speed at n ~ 2.6k.
+// State bits: up to four 64-slot masks per lane (n <= 16384).
+constexpr int kK2Masks = 4;
+
 template <int D>
 __device__ __forceinline__ void k2_apply_row(float *g, uint32_t *scr, const uint32_t (&colv)[D],
                                              const float (&valv)[D], int lane, int l, float sgn)
@@ -48,17 +55,18 @@ __device__ __forceinline__ void k2_apply_row(float *g, uint32_t *scr, const uint
     if (lane < D) {
         const uint32_t c = scr[lane];
         const float v = __uint_as_float(scr[D + lane]);
+        // padding entries are (self, +0.0f): several lanes may rewrite g[self] with the same value
         g[c] = g[c] + sgn * v;          // one fp32 add per touched field, in flip order (oracle 2b)
     }
 }
 
 template <int D>
-__global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs a)
+__global__ void __launch_bounds__(256) k_anneal_csr_rank1(EllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = blockIdx.x * kSparseWaves + wave;
+    const int r = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (r >= a.R) return;                                   // no workgroup-level synchronisation below
     const uint32_t gid = a.replica_offset + (uint32_t)r;
     const int n = a.n, slots = a.slots;
@@ -67,11 +75,19 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs 
     uint32_t *scr = reinterpret_cast<uint32_t *>(lds + wave * per_wave + (size_t)slots * 64 * 4);
     const uint8_t *init = static_cast<const uint8_t *>(a.init);
 
-    uint64_t xb = 0;                                        // bit t = x[64 t + lane]
+    uint64_t xb0 = 0, xb1 = 0, xb2 = 0, xb3 = 0;            // bit (t & 63) of mask (t >> 6) = x[64 t + lane]
+    auto get_bit = [&](int t) -> int {
+        const uint64_t m = (t < 64) ? xb0 : (t < 128) ? xb1 : (t < 192) ? xb2 : xb3;   // t is wave-uniform
+        return (int)((m >> (t & 63)) & 1ull);
+    };
+    auto xor_bit = [&](int t, uint64_t v) {
+        const uint64_t b = v << (t & 63);
+        if (t < 64) xb0 ^= b; else if (t < 128) xb1 ^= b; else if (t < 192) xb2 ^= b; else xb3 ^= b;
+    };
     if (init) {
         for (int t = 0; t < slots; ++t) {
             const int i = t * 64 + lane;
-            if (i < n && init[(size_t)r * n + i]) xb |= (1ull << t);
+            xor_bit(t, (i < n && init[(size_t)r * n + i]) ? 1ull : 0ull);
         }
     } else {
         for (int tg = 0; tg * 4 < slots; ++tg) {
@@ -80,7 +96,7 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs 
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int t = 4 * tg + c;
-                if (t < slots && t * 64 + lane < n) xb |= ((uint64_t)(w[c] >> 31) << t);
+                if (t < slots) xor_bit(t, (t * 64 + lane < n) ? (uint64_t)(w[c] >> 31) : 0ull);
             }
         }
     }
@@ -98,7 +114,7 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs 
         for (int t = 0; t < slots; ++t) g[t * 64 + lane] = a.lin[t * 64 + lane];
         int cnt = 0;
         for (int t = 0; t < slots; ++t) {
-            uint64_t m = __ballot((xb >> t) & 1ull);
+            uint64_t m = __ballot(get_bit(t));
             if (m == 0) continue;
             uint32_t colv[D];
             float valv[D];
@@ -132,7 +148,7 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs 
                 load_slot(t, colv, valv);
                 float thr = neglog_u(w[c]) * T;
                 if (t * 64 + lane >= n) thr = -INFINITY;
-                int xi = (int)((xb >> t) & 1ull);
+                int xi = get_bit(t);
                 uint64_t todo = ~0ull;
                 while (true) {
                     const float fi = g[t * 64 + lane] + a.c_pair * (float)(S - xi);
@@ -140,11 +156,12 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs 
                     const uint64_t m = __ballot(dE < thr) & todo;
                     if (m == 0) break;
                     const int l = __ffsll((unsigned long long)m) - 1;
-                    todo = (l == 63) ? 0ull : (~0ull << (l + 1));
+                    todo = (~0ull << l) << 1;
                     const int xl = __builtin_amdgcn_readlane(xi, l);
                     k2_apply_row<D>(g, scr, colv, valv, lane, l, xl ? -1.0f : 1.0f);
                     S += xl ? -1 : 1;
-                    if (lane == l) { xi ^= 1; xb ^= (1ull << t); }
+                    if (lane == l) xi ^= 1;
+                    xor_bit(t, lane == l ? 1ull : 0ull);
                     ++accepted;
                 }
             }
@@ -157,7 +174,7 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs 
     int cnt = 0;
     for (int t = 0; t < slots; ++t) {
         const int i = t * 64 + lane;
-        const uint32_t on = (uint32_t)((xb >> t) & 1ull);
+        const uint32_t on = (uint32_t)get_bit(t);
         xw[i] = on;
         if (i < n) dst[i] = (uint8_t)on;
         cnt += __popcll(__ballot(on));
@@ -165,7 +182,7 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs 
     double e = 0.0;
     for (int t = 0; t < slots; ++t) {
         const int i = t * 64 + lane;
-        if (!((xb >> t) & 1ull)) continue;
+        if (!get_bit(t)) continue;
         double acc = 0.0;
         for (int k = 0; k < D; ++k) {
             const uint32_t cc = a.ell_col[((size_t)t * D + k) * 64 + lane];
@@ -190,12 +207,12 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_csr_rank1(EllArgs 
 // (h sums taken in stored neighbour order, fp32 -- oracle 2c).  After a commit every later lane of the
 // slot re-evaluates from its register-resident adjacency row.
 template <int D>
-__global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_potts(EllArgs a)
+__global__ void __launch_bounds__(256) k_anneal_potts(EllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = blockIdx.x * kSparseWaves + wave;
+    const int r = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (r >= a.R) return;
     const uint32_t gid = a.replica_offset + (uint32_t)r;
     const int n = a.n, slots = a.slots, K = a.K;
@@ -247,14 +264,23 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_potts(EllArgs a)
                 int la = lab[i];
                 const int lb = (la + 1 + (int)(w2[c] % (uint32_t)(K - 1))) % K;
                 uint64_t todo = ~0ull;
-                while (true) {
-                    float ha = 0.0f, hb = 0.0f;
+                // h_a / h_b are summed from scratch (stored neighbour order) at the slot start and again
+                // only for lanes that have the committed variable among their neighbours -- for every
+                // other lane the cached sums ARE what a fresh evaluation would give; cluster sizes change
+                // for everybody and enter through cnt.
+                float ha = 0.0f, hb = 0.0f;
+                auto sum_h = [&]() {
+                    ha = 0.0f;
+                    hb = 0.0f;
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
                         const int lj = lab[colv[k]];
                         ha = ha + ((lj == la) ? valv[k] : 0.0f);
                         hb = hb + ((lj == lb) ? valv[k] : 0.0f);
                     }
+                };
+                sum_h();
+                while (true) {
                     const int ca = __shfl(cntv, la, 64), cb = __shfl(cntv, lb, 64);
                     const float ea = ha + a.c_pair * (float)(ca - 1);
                     const float eb = hb + a.c_pair * (float)cb;
@@ -262,12 +288,17 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_potts(EllArgs a)
                     const uint64_t m = __ballot(dE < thr) & todo;
                     if (m == 0) break;
                     const int l = __ffsll((unsigned long long)m) - 1;
-                    todo = (l == 63) ? 0ull : (~0ull << (l + 1));
+                    todo = (~0ull << l) << 1;
                     const int a_s = __builtin_amdgcn_readlane(la, l);
                     const int b_s = __builtin_amdgcn_readlane(lb, l);
                     if (lane == l) { lab[i] = (uint8_t)lb; la = lb; }
                     if (lane == a_s) cntv -= 1;
                     if (lane == b_s) cntv += 1;
+                    const uint32_t moved = (uint32_t)(t * 64 + l);
+                    bool touched = false;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) touched |= (colv[k] == moved);
+                    if (touched && lane > l) sum_h();          // padding (self) never equals `moved` for lane > l
                     ++accepted;
                 }
             }
@@ -299,11 +330,13 @@ __global__ void __launch_bounds__(kSparseWaves * 64) k_anneal_potts(EllArgs a)
 template <typename KernelT>
 int launch_sparse(KernelT kernel, const EllArgs &a, size_t lds_per_wave, hipStream_t st)
 {
-    const size_t lds = lds_per_wave * kSparseWaves;
+    int waves = kSparseWaves;                    // fewer replicas per workgroup when their LDS state is large
+    while (waves > 1 && lds_per_wave * waves > 160 * 1024) --waves;
+    const size_t lds = lds_per_wave * waves;
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "model too large for the LDS-resident sparse kernel (%zu B)", lds);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((a.R + kSparseWaves - 1) / kSparseWaves), dim3(kSparseWaves * 64), lds, st, a);
+    hipLaunchKernelGGL(kernel, dim3((a.R + waves - 1) / waves), dim3(waves * 64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
