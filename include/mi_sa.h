@@ -93,6 +93,18 @@ int mi_sa_debug_pace(mi_sa_problem *p, unsigned int *out, int words);
 int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
                  const double *betas, uint64_t seed, const void *init, int resync_interval);
 
+/* Extended form used by parallel tempering and by resumable runs:
+ *   sweep_offset          added to the sweep index in the random-number counter, so a run continued in
+ *                         pieces draws exactly the numbers of one long run;
+ *   MI_F_CONTINUE         start from the states the previous run left in HBM (same R; init must be NULL);
+ *   MI_F_BETA_PER_REPLICA betas has R entries: replica r anneals at the constant beta betas[r] for all
+ *                         num_sweeps sweeps of this call (one rung of a tempering ladder per replica). */
+#define MI_F_CONTINUE         1u
+#define MI_F_BETA_PER_REPLICA 2u
+int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
+                    const double *betas, uint64_t seed, const void *init, int resync_interval,
+                    uint32_t sweep_offset, uint32_t flags);
+
 int mi_sa_sync(mi_sa_problem *p);
 
 /* Device time of the anneal kernel(s) of the last mi_sa_anneal on this handle, from HIP events

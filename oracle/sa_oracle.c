@@ -140,11 +140,14 @@ static void field_init_dense(const float *Qs, int n, const uint8_t *x, float *f)
 int orc_sa_dense_philox(const float *Qs, int n, double offset, int R, uint32_t replica_offset,
                         int num_sweeps, const double *betas, uint64_t seed, const uint8_t *init,
                         int resync_interval, uint8_t *out_states, double *out_energy,
-                        uint64_t *out_stats)
+                        uint64_t *out_stats, uint32_t sweep_offset, int betas_per_replica)
 {
+    /* sweep_offset: added to the sweep index in the RNG counter (a run continued in pieces draws the
+     * numbers of one long run).  betas_per_replica: betas has R entries, replica r anneals at betas[r]. */
     uint64_t tot_prop = 0, tot_acc = 0;
-    float *temps = (float *)malloc(sizeof(float) * (size_t)(num_sweeps > 0 ? num_sweeps : 1));
-    for (int s = 0; s < num_sweeps; ++s) temps[s] = (float)(1.0 / betas[s]);
+    const int nb = betas_per_replica ? R : num_sweeps;
+    float *temps = (float *)malloc(sizeof(float) * (size_t)(nb > 0 ? nb : 1));
+    for (int s = 0; s < nb; ++s) temps[s] = (float)(1.0 / betas[s]);
 #pragma omp parallel for schedule(dynamic) reduction(+ : tot_prop, tot_acc)
     for (int r = 0; r < R; ++r) {
         uint32_t g = replica_offset + (uint32_t)r;
@@ -155,9 +158,9 @@ int orc_sa_dense_philox(const float *Qs, int n, double offset, int R, uint32_t r
             for (int i = 0; i < n; ++i) x[i] = (uint8_t)(chain_word(seed, (uint32_t)i, 0, g, 1) >> 31);
         field_init_dense(Qs, n, x, f);
         for (int s = 0; s < num_sweeps; ++s) {
-            float T = temps[s];
+            float T = temps[betas_per_replica ? r : s];
             for (int i = 0; i < n; ++i) {
-                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s, g, 0)) * T;
+                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, g, 0)) * T;
                 float dE = x[i] ? -f[i] : f[i];
                 ++tot_prop;
                 if (dE < thr) {
@@ -218,11 +221,12 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
                             float c_pair, int n, double offset, int R, uint32_t replica_offset,
                             int num_sweeps, const double *betas, uint64_t seed, const uint8_t *init,
                             int resync_interval, uint8_t *out_states, double *out_energy,
-                            uint64_t *out_stats)
+                            uint64_t *out_stats, uint32_t sweep_offset, int betas_per_replica)
 {
     uint64_t tot_prop = 0, tot_acc = 0;
-    float *temps = (float *)malloc(sizeof(float) * (size_t)(num_sweeps > 0 ? num_sweeps : 1));
-    for (int s = 0; s < num_sweeps; ++s) temps[s] = (float)(1.0 / betas[s]);
+    const int nb = betas_per_replica ? R : num_sweeps;
+    float *temps = (float *)malloc(sizeof(float) * (size_t)(nb > 0 ? nb : 1));
+    for (int s = 0; s < nb; ++s) temps[s] = (float)(1.0 / betas[s]);
 #pragma omp parallel for schedule(dynamic) reduction(+ : tot_prop, tot_acc)
     for (int r = 0; r < R; ++r) {
         uint32_t gid = replica_offset + (uint32_t)r;
@@ -234,9 +238,9 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
             for (int i = 0; i < n; ++i) x[i] = (uint8_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) >> 31);
         field_init_csr(rowptr, col, val, lin, n, x, g, &S);
         for (int s = 0; s < num_sweeps; ++s) {
-            float T = temps[s];
+            float T = temps[betas_per_replica ? r : s];
             for (int i = 0; i < n; ++i) {
-                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s, gid, 0)) * T;
+                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
                 float fi = g[i] + c_pair * (float)(S - (int)x[i]);
                 float dE = x[i] ? -fi : fi;
                 ++tot_prop;
@@ -285,11 +289,13 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
 int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, float c_pair, int n,
                          int K, double lin_offset, int R, uint32_t replica_offset, int num_sweeps,
                          const double *betas, uint64_t seed, const uint16_t *init,
-                         uint16_t *out_labels, double *out_energy, uint64_t *out_stats)
+                         uint16_t *out_labels, double *out_energy, uint64_t *out_stats,
+                         uint32_t sweep_offset, int betas_per_replica)
 {
     uint64_t tot_prop = 0, tot_acc = 0;
-    float *temps = (float *)malloc(sizeof(float) * (size_t)(num_sweeps > 0 ? num_sweeps : 1));
-    for (int s = 0; s < num_sweeps; ++s) temps[s] = (float)(1.0 / betas[s]);
+    const int nb = betas_per_replica ? R : num_sweeps;
+    float *temps = (float *)malloc(sizeof(float) * (size_t)(nb > 0 ? nb : 1));
+    for (int s = 0; s < nb; ++s) temps[s] = (float)(1.0 / betas[s]);
 #pragma omp parallel for schedule(dynamic) reduction(+ : tot_prop, tot_acc)
     for (int r = 0; r < R; ++r) {
         uint32_t gid = replica_offset + (uint32_t)r;
@@ -301,10 +307,10 @@ int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, fl
                 l[i] = (uint16_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) % (uint32_t)K);
         for (int i = 0; i < n; ++i) cnt[l[i]]++;
         for (int s = 0; s < num_sweeps; ++s) {
-            float T = temps[s];
+            float T = temps[betas_per_replica ? r : s];
             for (int i = 0; i < n && K > 1; ++i) {
                 int a = l[i];
-                int b = (a + 1 + (int)(chain_word(seed, (uint32_t)i, (uint32_t)s, gid, 2) % (uint32_t)(K - 1))) % K;
+                int b = (a + 1 + (int)(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 2) % (uint32_t)(K - 1))) % K;
                 float ha = 0.0f, hb = 0.0f;
                 for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
                     int lj = l[col[e]];
@@ -314,7 +320,7 @@ int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, fl
                 float ea = ha + c_pair * (float)(cnt[a] - 1);
                 float eb = hb + c_pair * (float)cnt[b];
                 float dE = eb - ea;
-                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s, gid, 0)) * T;
+                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
                 ++tot_prop;
                 if (dE < thr) {
                     l[i] = (uint16_t)b;

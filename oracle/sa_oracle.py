@@ -50,7 +50,8 @@ def chain_word(seed, i, s, g, tag):
 
 
 def sa_dense_philox(Qs, R, betas, seed, offset=0.0, replica_offset=0, init=None,
-                    resync_interval=0):
+                    resync_interval=0, sweep_offset=0, num_sweeps=None):
+    """betas: one per sweep, or (num_sweeps given) one per replica held for num_sweeps sweeps."""
     Qs = np.ascontiguousarray(Qs, dtype=np.float32)
     n = Qs.shape[0]
     betas = np.ascontiguousarray(betas, dtype=np.float64)
@@ -61,15 +62,15 @@ def sa_dense_philox(Qs, R, betas, seed, offset=0.0, replica_offset=0, init=None,
         init = np.ascontiguousarray(init, dtype=np.uint8)
     rc = lib().orc_sa_dense_philox(
         _p(Qs, C.c_float), C.c_int(n), C.c_double(offset), C.c_int(R), C.c_uint32(replica_offset),
-        C.c_int(len(betas)), _p(betas, C.c_double), C.c_uint64(seed), _p(init, C.c_uint8),
-        C.c_int(resync_interval), _p(states, C.c_uint8), _p(energy, C.c_double),
-        _p(stats, C.c_uint64))
+        C.c_int(len(betas) if num_sweeps is None else num_sweeps), _p(betas, C.c_double), C.c_uint64(seed),
+        _p(init, C.c_uint8), C.c_int(resync_interval), _p(states, C.c_uint8), _p(energy, C.c_double),
+        _p(stats, C.c_uint64), C.c_uint32(sweep_offset), C.c_int(0 if num_sweeps is None else 1))
     assert rc == 0
     return states, energy, stats
 
 
 def sa_csr_rank1_philox(rowptr, col, val, lin, c_pair, R, betas, seed, offset=0.0,
-                        replica_offset=0, init=None, resync_interval=0):
+                        replica_offset=0, init=None, resync_interval=0, sweep_offset=0, num_sweeps=None):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     col = np.ascontiguousarray(col, dtype=np.int32)
     val = np.ascontiguousarray(val, dtype=np.float32)
@@ -84,15 +85,15 @@ def sa_csr_rank1_philox(rowptr, col, val, lin, c_pair, R, betas, seed, offset=0.
     rc = lib().orc_sa_csr_rank1_philox(
         _p(rowptr, C.c_int), _p(col, C.c_int), _p(val, C.c_float), _p(lin, C.c_float),
         C.c_float(c_pair), C.c_int(n), C.c_double(offset), C.c_int(R), C.c_uint32(replica_offset),
-        C.c_int(len(betas)), _p(betas, C.c_double), C.c_uint64(seed), _p(init, C.c_uint8),
-        C.c_int(resync_interval), _p(states, C.c_uint8), _p(energy, C.c_double),
-        _p(stats, C.c_uint64))
+        C.c_int(len(betas) if num_sweeps is None else num_sweeps), _p(betas, C.c_double), C.c_uint64(seed),
+        _p(init, C.c_uint8), C.c_int(resync_interval), _p(states, C.c_uint8), _p(energy, C.c_double),
+        _p(stats, C.c_uint64), C.c_uint32(sweep_offset), C.c_int(0 if num_sweeps is None else 1))
     assert rc == 0
     return states, energy, stats
 
 
 def potts_csr_philox(rowptr, col, val, c_pair, n, K, R, betas, seed, lin_offset=0.0,
-                     replica_offset=0, init=None):
+                     replica_offset=0, init=None, sweep_offset=0, num_sweeps=None):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     col = np.ascontiguousarray(col, dtype=np.int32)
     val = np.ascontiguousarray(val, dtype=np.float32)
@@ -105,8 +106,9 @@ def potts_csr_philox(rowptr, col, val, c_pair, n, K, R, betas, seed, lin_offset=
     rc = lib().orc_potts_csr_philox(
         _p(rowptr, C.c_int), _p(col, C.c_int), _p(val, C.c_float), C.c_float(c_pair), C.c_int(n),
         C.c_int(K), C.c_double(lin_offset), C.c_int(R), C.c_uint32(replica_offset),
-        C.c_int(len(betas)), _p(betas, C.c_double), C.c_uint64(seed), _p(init, C.c_uint16),
-        _p(labels, C.c_uint16), _p(energy, C.c_double), _p(stats, C.c_uint64))
+        C.c_int(len(betas) if num_sweeps is None else num_sweeps), _p(betas, C.c_double), C.c_uint64(seed),
+        _p(init, C.c_uint16), _p(labels, C.c_uint16), _p(energy, C.c_double), _p(stats, C.c_uint64),
+        C.c_uint32(sweep_offset), C.c_int(0 if num_sweeps is None else 1))
     assert rc == 0
     return labels, energy, stats
 

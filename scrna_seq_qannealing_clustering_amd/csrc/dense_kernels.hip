@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
         if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
         if (init_now) dense_field_init<NT>(f, rsrc, diag_row, xb, lane);
         // temperature of this sweep as a scalar (SGPR) operand
-        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
+            __float_as_int(a.temps[a.temps_per_replica ? r : s])));
         uint32_t w[4];
         static_for<0, NT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
             const int left = nn - t * 64;       // variables remaining from this slot on (scalar)
             if (left > 0) {                     // wave-uniform
                 if constexpr ((t & 3) == 0)
-                    philox4x32_10((uint32_t)((t >> 2) * 64 + ln), (uint32_t)s, g, 0u, a.seed_lo,
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + ln), (uint32_t)s + a.sweep_offset, g, 0u, a.seed_lo,
                                   a.seed_hi, w);
                 float thr = neglog_u(w[t & 3]) * T;
                 if (ln >= left) thr = -INFINITY;
@@ -342,7 +343,8 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
 #pragma unroll 1
             for (int u = 0; u < C::U - 1; ++u) issue_unit();
         }
-        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
+            __float_as_int(a.temps[a.temps_per_replica ? (active ? r : 0) : s])));
         uint32_t w[4];
         static_for<0, NT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -352,7 +354,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
             const int left = nn - t * 64;
             if (left > 0) {                     // wave-uniform, identical in every wave of the block
                 if constexpr ((t & 3) == 0)
-                    philox4x32_10((uint32_t)((t >> 2) * 64 + ln), (uint32_t)s, g, 0u, a.seed_lo,
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + ln), (uint32_t)s + a.sweep_offset, g, 0u, a.seed_lo,
                                   a.seed_hi, w);
                 float thr = neglog_u(w[t & 3]) * T;
                 if (ln >= left || !active || (a.debug & 2)) thr = -INFINITY;

@@ -374,22 +374,29 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     return fail(MI_EINVAL, "unknown option '%s'", key);
 }
 
-int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
-                 const double *betas, uint64_t seed, const void *init, int resync_interval)
+int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
+                    const double *betas, uint64_t seed, const void *init, int resync_interval,
+                    uint32_t sweep_offset, uint32_t flags)
 {
+    const bool cont = (flags & MI_F_CONTINUE) != 0, per_replica = (flags & MI_F_BETA_PER_REPLICA) != 0;
+    const int num_betas = per_replica ? R : num_sweeps;
+    if (flags & ~(uint32_t)(MI_F_CONTINUE | MI_F_BETA_PER_REPLICA)) return fail(MI_EINVAL, "unknown flags 0x%x", flags);
     if (!p) return fail(MI_EINVAL, "NULL problem");
     if (R < 1) return fail(MI_EINVAL, "R must be >= 1 (got %d)", R);
     if (num_sweeps < 0) return fail(MI_EINVAL, "num_sweeps must be >= 0");
-    if (num_sweeps > 0 && !betas) return fail(MI_EINVAL, "betas is NULL");
+    if (num_betas > 0 && num_sweeps > 0 && !betas) return fail(MI_EINVAL, "betas is NULL");
+    if (cont && (!p || !p->has_run || p->last_R != R))
+        return fail(MI_ESTATE, "MI_F_CONTINUE needs a previous run with the same number of replicas");
+    if (cont && init) return fail(MI_EINVAL, "MI_F_CONTINUE and init are mutually exclusive");
     if (resync_interval < 0) return fail(MI_EINVAL, "resync_interval must be >= 0");
-    for (int s = 0; s < num_sweeps; ++s)
+    for (int s = 0; s < (num_sweeps > 0 ? num_betas : 0); ++s)
         if (!(betas[s] > 0.0) || !std::isfinite(betas[s]))
             return fail(MI_EINVAL, "betas[%d] = %g is not a positive finite number", s, betas[s]);
     HIP_TRY(hipSetDevice(p->device));
-    int rc = ensure_run_buffers(p, R, num_sweeps, init != nullptr);
+    int rc = ensure_run_buffers(p, R, num_betas, init != nullptr);
     if (rc) return rc;
-    std::vector<float> temps((size_t)(num_sweeps > 0 ? num_sweeps : 1), 1.0f);
-    for (int s = 0; s < num_sweeps; ++s) temps[s] = (float)(1.0 / betas[s]);
+    std::vector<float> temps((size_t)(num_betas > 0 ? num_betas : 1), 1.0f);
+    for (int s = 0; s < (num_sweeps > 0 ? num_betas : 0); ++s) temps[s] = (float)(1.0 / betas[s]);
     // pageable-host async copies are staged synchronously by the runtime: the vector may go away
     HIP_TRY(hipMemcpyAsync(p->d_temps, temps.data(), temps.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
     if (init)
@@ -400,11 +407,11 @@ int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweep
     if (p->kind == MI_KIND_DENSE) {
         DenseArgs a;
         a.Qp = p->d_Qp; a.temps = p->d_temps;
-        a.init = init ? (const uint8_t *)p->d_init : nullptr;
+        a.init = cont ? (const uint8_t *)p->d_states : (init ? (const uint8_t *)p->d_init : nullptr);
         a.states = (uint8_t *)p->d_states; a.energy = p->d_energy; a.stats = p->d_stats; a.pace = nullptr;
         a.offset = p->offset; a.n = p->n; a.R = R; a.num_sweeps = num_sweeps; a.resync = resync_interval;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-        a.debug = p->opt_debug;
+        a.debug = p->opt_debug; a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
         rc = dispatch_dense(p, a, p->stream);
         if (rc) return rc;
@@ -412,10 +419,11 @@ int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweep
     } else {
         EllArgs a;
         a.ell_col = p->d_ell_col; a.ell_val = p->d_ell_val; a.lin = p->d_lin; a.temps = p->d_temps;
-        a.init = init ? p->d_init : nullptr; a.states = p->d_states; a.energy = p->d_energy; a.stats = p->d_stats;
+        a.init = cont ? p->d_states : (init ? p->d_init : nullptr); a.states = p->d_states; a.energy = p->d_energy; a.stats = p->d_stats;
         a.c_pair = p->c_pair; a.offset = p->offset; a.n = p->n; a.K = p->K; a.R = R; a.num_sweeps = num_sweeps;
         a.resync = resync_interval; a.slots = p->slots; a.D = p->D;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+        a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
         if (p->kind == MI_KIND_POTTS_CSR && init) {
             // labels must be < K: validated on the host copy (the device trusts them as cnt[] indices)
             const uint16_t *l = static_cast<const uint16_t *>(init);
@@ -429,6 +437,12 @@ int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweep
     }
     p->last_R = R; p->last_offset = replica_offset; p->has_run = true;
     return MI_OK;
+}
+
+int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
+                 const double *betas, uint64_t seed, const void *init, int resync_interval)
+{
+    return mi_sa_anneal_ex(p, R, replica_offset, num_sweeps, betas, seed, init, resync_interval, 0u, 0u);
 }
 
 int mi_sa_sync(mi_sa_problem *p)

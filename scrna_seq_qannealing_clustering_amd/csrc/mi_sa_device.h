@@ -177,6 +177,8 @@ struct DenseArgs {
     double offset;
     int n, R, num_sweeps, resync;
     uint32_t replica_offset, seed_lo, seed_hi;
+    uint32_t sweep_offset;  // added to the sweep index in the RNG counter (continuation of an earlier run)
+    int temps_per_replica;  // 0: temps[s] per sweep; 1: temps[r], one constant temperature per replica
     int debug;              // diagnostic timing builds only: bit0 = skip LDS-DMA, bit1 = accept nothing
 };
 
@@ -200,6 +202,8 @@ struct EllArgs {
     double offset;             // K2: offset; K3: lin_offset
     int n, K, R, num_sweeps, resync, slots, D;
     uint32_t replica_offset, seed_lo, seed_hi;
+    uint32_t sweep_offset;     // see DenseArgs
+    int temps_per_replica;
 };
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_potts(const EllArgs &, hipStream_t);

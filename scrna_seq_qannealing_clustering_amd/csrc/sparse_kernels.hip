@@ -135,10 +135,11 @@ __global__ void __launch_bounds__(256) k_anneal_csr_rank1(EllArgs a)
         bool init_now = (s == 0);
         if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
         if (init_now) field_init();
-        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
+            __float_as_int(a.temps[a.temps_per_replica ? r : s])));
         for (int tg = 0; tg * 4 < slots; ++tg) {
             uint32_t w[4];
-            slot_words(w, tg, lane, (uint32_t)s, gid, 0u, a.seed_lo, a.seed_hi);
+            slot_words(w, tg, lane, (uint32_t)s + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int t = 4 * tg + c;
@@ -242,11 +243,12 @@ __global__ void __launch_bounds__(256) k_anneal_potts(EllArgs a)
 
     unsigned long long accepted = 0;
     for (int s = 0; s < a.num_sweeps && K > 1; ++s) {
-        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
+            __float_as_int(a.temps[a.temps_per_replica ? r : s])));
         for (int tg = 0; tg * 4 < slots; ++tg) {
             uint32_t w0[4], w2[4];
-            slot_words(w0, tg, lane, (uint32_t)s, gid, 0u, a.seed_lo, a.seed_hi);
-            slot_words(w2, tg, lane, (uint32_t)s, gid, 2u, a.seed_lo, a.seed_hi);
+            slot_words(w0, tg, lane, (uint32_t)s + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
+            slot_words(w2, tg, lane, (uint32_t)s + a.sweep_offset, gid, 2u, a.seed_lo, a.seed_hi);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int t = 4 * tg + c;

@@ -99,19 +99,29 @@ class Problem:
         return np.uint16 if self.kind == _lib.KIND_POTTS_CSR else np.uint8
 
     def anneal(self, num_reads: int, betas, seed: int, replica_offset: int = 0,
-               initial_states: Optional[np.ndarray] = None, resync_interval: int = 0):
+               initial_states: Optional[np.ndarray] = None, resync_interval: int = 0,
+               sweep_offset: int = 0, continue_run: bool = False, num_sweeps: Optional[int] = None):
+        """``betas``: one per sweep (default), or -- when ``num_sweeps`` is given -- one per REPLICA, held
+        constant for ``num_sweeps`` sweeps (a tempering rung).  ``continue_run`` starts from the states the
+        previous call left on the device; ``sweep_offset`` continues its random stream."""
         betas = np.ascontiguousarray(betas, dtype=np.float64)
+        per_replica = num_sweeps is not None
+        if per_replica and len(betas) != num_reads:
+            raise ValueError("per-replica betas need one entry per replica")
+        flags = (1 if continue_run else 0) | (2 if per_replica else 0)
+        sweeps = int(num_sweeps) if per_replica else len(betas)
         init = None
         if initial_states is not None:
             init = np.ascontiguousarray(initial_states, dtype=self.state_dtype)
             if init.shape != (num_reads, self.n):
                 raise ValueError("initial_states must have shape (num_reads, n) = (%d, %d)"
                                  % (num_reads, self.n))
-        _lib.check(_lib.load().mi_sa_anneal(
-            self._h, int(num_reads), C.c_uint32(int(replica_offset) & 0xFFFFFFFF), len(betas),
+        _lib.check(_lib.load().mi_sa_anneal_ex(
+            self._h, int(num_reads), C.c_uint32(int(replica_offset) & 0xFFFFFFFF), sweeps,
             _ptr(betas, C.c_double), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
-            init.ctypes.data_as(C.c_void_p) if init is not None else None, int(resync_interval)))
-        self._last = (int(num_reads), len(betas))
+            init.ctypes.data_as(C.c_void_p) if init is not None else None, int(resync_interval),
+            C.c_uint32(int(sweep_offset) & 0xFFFFFFFF), C.c_uint32(flags)))
+        self._last = (int(num_reads), sweeps)
 
     def sync(self):
         _lib.check(_lib.load().mi_sa_sync(self._h))

@@ -1,0 +1,165 @@
+"""Parallel tempering: exchange rule (CPU), 2-rank gloo equivalence with the oracle as the engine (CPU),
+and -- on the GPU -- continuation / per-replica-beta parity of the kernels plus an end-to-end PT run."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_fixture
+from oracle import sa_oracle as so
+from scrna_seq_qannealing_clustering_amd import distributed as D
+from scrna_seq_qannealing_clustering_amd import models, tempering
+
+
+class OracleEngine:
+    """The CPU oracle behind the tempering driver's engine interface (tests only)."""
+
+    def __init__(self, kind, args, seed, **kw):
+        self.kind, self.args, self.seed, self.kw = kind, args, seed, kw
+        self.st = self.en = None
+
+    def round(self, betas_local, num_sweeps, sweep_offset, replica_offset, first, initial_states=None):
+        init = initial_states if first else self.st
+        fn = {"dense": so.sa_dense_philox, "csr": so.sa_csr_rank1_philox, "potts": so.potts_csr_philox}[self.kind]
+        self.st, self.en, _ = fn(*self.args, len(betas_local), betas_local, self.seed,
+                                 replica_offset=replica_offset, init=init, sweep_offset=sweep_offset,
+                                 num_sweeps=num_sweeps, **self.kw)
+
+    def energies(self):
+        return self.en
+
+    def states(self):
+        return self.st
+
+
+def potts_case(name="blobs", K=3, gamma=0.05):
+    fx = load_fixture(name)
+    pm = models.build_dqm_potts(fx.graph(), K, gamma)
+    args = (pm.rowptr, pm.col, pm.val.astype(np.float32), float(np.float32(pm.c_pair)), 256, K)
+    return fx, pm, args
+
+
+def test_exchange_rule_is_metropolis_and_moves_rungs_only():
+    ladder = tempering.geometric_ladder(0.1, 10.0, 4)
+    rung = np.arange(8) % 4
+    en = np.array([5.0, 1.0, 2.0, 3.0, 0.0, 0.0, 0.0, 0.0])
+    # pair (0,1) of chain 0: hotter replica has HIGHER energy -> arg = (b0-b1)(E0-E1) < 0 -> random;
+    # with energies reversed the swap is certain
+    new, p, a = tempering.exchange_step(np.array([1.0, 5.0, 2.0, 3.0, 0, 0, 0, 0]), rung, ladder, 4, 0, 7)
+    assert p == 4 and new[0] == 1 and new[1] == 0                    # certain swap: colder rung gets lower E
+    assert sorted(new[:4].tolist()) == [0, 1, 2, 3] and sorted(new[4:].tolist()) == [0, 1, 2, 3]
+    n2, _, _ = tempering.exchange_step(en, rung, ladder, 4, 1, 7)   # odd round: pairs (1,2) only
+    assert n2[0] == 0 and n2[3] == 3
+    # deterministic in (seed, round)
+    x1 = tempering.exchange_step(en, rung, ladder, 4, 0, 99)[0]
+    x2 = tempering.exchange_step(en, rung, ladder, 4, 0, 99)[0]
+    assert np.array_equal(x1, x2)
+    with pytest.raises(ValueError):
+        tempering.geometric_ladder(1, 2, 1)
+
+
+def test_oracle_continuation_equals_one_long_run():
+    """sweep_offset + initial states = resumable runs (the checkpoint/resume of SURVEY.md section 5)."""
+    fx, pm, args = potts_case()
+    betas = np.geomspace(0.5, 20.0, 12)
+    full, efull, _ = so.potts_csr_philox(*args, 4, betas, 3, lin_offset=pm.lin_offset)
+    a, _, _ = so.potts_csr_philox(*args, 4, betas[:5], 3, lin_offset=pm.lin_offset)
+    b, eb, _ = so.potts_csr_philox(*args, 4, betas[5:], 3, lin_offset=pm.lin_offset, init=a, sweep_offset=5)
+    assert np.array_equal(full, b) and np.allclose(efull, eb)
+
+
+def _pt_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env(backend="gloo")
+    fx, pm, args = potts_case()
+    eng = OracleEngine("potts", args, 11, lin_offset=pm.lin_offset)
+    out = tempering.parallel_tempering(eng, tempering.geometric_ladder(0.5, 30.0, 4), chains=3, rounds=6,
+                                       sweeps_per_round=5, seed=11, rank=rank, world=world)
+    np.savez(os.path.join(out_dir, "pt%d.npz" % rank), energies=out["energies"], rung=out["rung"],
+             states=out["local_states"], lo=out["local_range"][0], hi=out["local_range"][1],
+             swap=out["swap_rate"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_tempering_equals_single_process(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_pt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    fx, pm, args = potts_case()
+    eng = OracleEngine("potts", args, 11, lin_offset=pm.lin_offset)
+    ref = tempering.parallel_tempering(eng, tempering.geometric_ladder(0.5, 30.0, 4), chains=3, rounds=6,
+                                       sweeps_per_round=5, seed=11)
+    outs = [np.load(os.path.join(str(tmp_path), "pt%d.npz" % r)) for r in range(2)]
+    for o in outs:
+        assert np.array_equal(o["energies"], ref["energies"])          # all-gathered, global order
+        assert np.array_equal(o["rung"], ref["rung"])                  # same exchange decisions everywhere
+    states = np.concatenate([outs[0]["states"], outs[1]["states"]])
+    assert np.array_equal(states, ref["local_states"])                # shards == single process
+    assert 0.0 < float(outs[0]["swap"]) <= 1.0
+    assert sorted(ref["rung"][:4].tolist()) == [0, 1, 2, 3]
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense", "csr", "potts"])
+def test_gpu_continuation_and_per_replica_beta_parity(kind):
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    fx = load_fixture("aniso")
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    if kind == "dense":
+        Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))
+        mk, oargs, ofn, okw = (lambda: Problem.dense(Qs)), (Qs,), so.sa_dense_philox, {}
+    elif kind == "csr":
+        a = (m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32), float(np.float32(m.c_pair)))
+        mk, oargs, ofn, okw = (lambda: Problem.csr_rank1(*a)), a, so.sa_csr_rank1_philox, {}
+    else:
+        _, pm, a = potts_case("aniso", 8, 0.005)
+        mk, oargs, ofn, okw = (lambda: Problem.potts_csr(*a, lin_offset=pm.lin_offset)), a, so.potts_csr_philox, \
+            {"lin_offset": pm.lin_offset}
+    R = 40                                                    # dense: the workgroup kernel, ragged last group
+    betas = np.geomspace(0.01, 5.0, 14)
+    full, efull, _ = ofn(*oargs, R, betas, 5, replica_offset=2, **okw)
+    with mk() as p:
+        p.anneal(R, betas[:6], 5, replica_offset=2)
+        p.anneal(R, betas[6:], 5, replica_offset=2, continue_run=True, sweep_offset=6)
+        st, en, _ = p.fetch()
+        assert np.array_equal(st, full) and np.allclose(en, efull, rtol=1e-9, atol=1e-9)
+        # one constant beta per replica (a tempering rung), 7 sweeps
+        per = np.geomspace(0.02, 8.0, R)
+        p.anneal(R, per, 9, replica_offset=2, num_sweeps=7, sweep_offset=100)
+        st2, en2, info2 = p.fetch()
+    ost, oen, ostats = ofn(*oargs, R, per, 9, replica_offset=2, sweep_offset=100, num_sweeps=7, **okw)
+    assert np.array_equal(st2, ost) and info2["accepted"] == int(ostats[1])
+    assert np.allclose(en2, oen, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_parallel_tempering_matches_oracle_engine_and_improves_on_sa():
+    """BASELINE config 5 in miniature: DQM K=3 on the reference's blobs graph, 8 rungs x 8 chains."""
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    fx, pm, args = potts_case("blobs", 3, 0.05)
+    ladder = tempering.geometric_ladder(0.3, 40.0, 8)
+    with Problem.potts_csr(*args, lin_offset=pm.lin_offset) as p:
+        out = tempering.parallel_tempering(tempering.ProblemEngine(p, seed=4), ladder, chains=8, rounds=20,
+                                           sweeps_per_round=10, seed=4)
+    ref = tempering.parallel_tempering(OracleEngine("potts", args, 4, lin_offset=pm.lin_offset), ladder,
+                                       chains=8, rounds=20, sweeps_per_round=10, seed=4)
+    assert np.array_equal(out["local_states"], ref["local_states"])     # same chain, same exchanges
+    assert np.array_equal(out["rung"], ref["rung"])
+    assert np.allclose(out["energies"], ref["energies"], rtol=1e-9)
+    assert 0.05 < out["swap_rate"] < 1.0
+    assert out["history"][-1] <= out["history"][0]
+    # the three blobs are disconnected components: labels = components is the natural optimum
+    comp = fx.components()
+    ids = {c: k for k, c in enumerate(sorted(set(comp.tolist())))}
+    e_comp = pm.energies(np.array([[ids[int(c)] for c in comp]]))[0]
+    assert out["best_energy"] <= e_comp * (1 - 1e-6)          # device energies use the fp32-stored coefficients
