@@ -133,7 +133,12 @@ def main():
     from scrna_seq_qannealing_clustering_amd import distributed as D
     from scrna_seq_qannealing_clustering_amd.engine import Problem
 
-    rank, world, local = D.init_from_env()
+    # MI_BENCH_BACKEND=gloo + MI_BENCH_DEVICE=0 rehearse the N>1 code path with several ranks on ONE GPU
+    # (the real multi-GPU run uses RCCL, one rank per GPU, launched by torch.distributed.run)
+    rank, world, local = D.init_from_env(backend=os.environ.get("MI_BENCH_BACKEND"))
+    if "MI_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["MI_BENCH_DEVICE"])
+    coll_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -171,7 +176,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

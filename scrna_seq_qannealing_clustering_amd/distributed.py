@@ -60,6 +60,7 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL on this driver)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
