@@ -17,10 +17,12 @@ ap.add_argument("--sweeps", type=int, default=100)
 ap.add_argument("--replicas", type=int, default=4096)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--beta-range", default=None, help="lo,hi (default: the model's neal-style range)")
 ap.add_argument("arms", nargs="*", default=["pace=0", "pace=1"])
 a = ap.parse_args()
 m, Qs, betas_full, _, _graph = bench.build_workload()
-betas = models.make_beta_schedule(a.sweeps, models.default_beta_range(m))
+brange = tuple(float(x) for x in a.beta_range.split(',')) if a.beta_range else models.default_beta_range(m)
+betas = models.make_beta_schedule(a.sweeps, brange)
 n = Qs.shape[0]
 ref = None
 with Problem.dense(Qs) as p:

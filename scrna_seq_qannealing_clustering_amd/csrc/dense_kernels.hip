@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
 //   lockstep: the 16 waves rendezvous once per unit (GR rows); inside a unit each wave runs its own
 //         accept/commit loop on the unit's rows.
 constexpr int kWgWaves = 16;
-constexpr int kLdsBytes = 160 * 1024;
+constexpr int kLdsBytes = 160 * 1024 - 256;   // ring budget; the last 256 bytes hold the sweep-mode words
 
 template <int NT, int GR>
 struct WgCfg {
@@ -243,6 +243,40 @@ __device__ __forceinline__ void dense_add_row_lds(f32x2 (&f)[NT / 2], const char
     }
 }
 
+// f (+)= s * Q2[row] straight from L2 / Infinity Cache (K1-style buffer loads) into the pair layout of
+// K1w: used by the ON-DEMAND sweeps, where accepted flips are too rare to be worth streaming Q.  Two
+// halves, so that at most NT/2+2 extra registers are live.
+template <int NT>
+__device__ __forceinline__ void dense_add_row_pairs(f32x2 (&f)[NT / 2], __amdgpu_buffer_rsrc_t rsrc, int row,
+                                                    int lane, float s)
+{
+    constexpr int G = NT / 4, H = (G + 1) / 2;
+    const int voff = lane * 16;
+    const int soff = row * (NT * 256);
+    const f32x2 s2 = {s, s};
+    {
+        u32x4 q[H];
+#pragma unroll
+        for (int g = 0; g < H; ++g) q[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + g * 1024, 0);
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+            f[2 * g + 0] = __builtin_elementwise_fma(s2, f32x2{__uint_as_float(q[g].x), __uint_as_float(q[g].y)}, f[2 * g + 0]);
+            f[2 * g + 1] = __builtin_elementwise_fma(s2, f32x2{__uint_as_float(q[g].z), __uint_as_float(q[g].w)}, f[2 * g + 1]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G > H) {
+        u32x4 q[G - H];
+#pragma unroll
+        for (int g = H; g < G; ++g) q[g - H] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + g * 1024, 0);
+#pragma unroll
+        for (int g = H; g < G; ++g) {
+            f[2 * g + 0] = __builtin_elementwise_fma(s2, f32x2{__uint_as_float(q[g - H].x), __uint_as_float(q[g - H].y)}, f[2 * g + 0]);
+            f[2 * g + 1] = __builtin_elementwise_fma(s2, f32x2{__uint_as_float(q[g - H].z), __uint_as_float(q[g - H].w)}, f[2 * g + 1]);
+        }
+    }
+}
+
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from (buffer base + voff + soff) to lds_dst + lane*16
 // (buffer_load_dwordx4 ... lds).  Kept in a non-template __device__ function: inside a kernel TEMPLATE
 // the builtin makes hipcc silently drop the kernel's host-side launch stub (undefined symbol at load).
@@ -256,7 +290,9 @@ template <int NT, int GR>
 __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
 {
     using C = WgCfg<NT, GR>;
-    __shared__ __attribute__((aligned(16))) char ring[C::U * C::UNITB];
+    __shared__ __attribute__((aligned(16))) char ring[C::U * C::UNITB + 256];
+    // last 256 bytes: three rotating words counting the workgroup's accepted flips per sweep
+    unsigned int *flips_word = reinterpret_cast<unsigned int *>(ring + C::U * C::UNITB);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -266,7 +302,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
     const int n = a.n;
     const int slots_used = (n + 63) >> 6;
     const int units_per_sweep = slots_used * (64 / GR);
-    const int total_units = a.num_sweeps * units_per_sweep;      // host checks it fits an int
+    const int total_units = units_per_sweep;     // the ring is primed and drained once per STREAMED sweep
 
     // rows 0..64*slots_used-1 (zero rows past n) + the diagonal row at index 64*slots_used
     const int diag_row = slots_used * 64;
@@ -326,9 +362,18 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
         }
     };
 
+    // Sweep mode (identical in all 16 waves): STREAM = Q through the LDS ring, one rendezvous per unit;
+    // ON-DEMAND = no streaming and no rendezvous, the (rare) accepted flips fetch their row from L2.
+    // Chosen per sweep from the workgroup's accepted-flip count of the previous sweep: a geometric
+    // schedule spends most of its sweeps cold (acceptance << 1 %), where streaming 30 MB per sweep per
+    // workgroup to serve a handful of flips is all overhead.  Results do not depend on the mode.
+    if (threadIdx.x < 3) flips_word[threadIdx.x] = 0u;
+    __syncthreads();
+    bool stream = true;
     unsigned long long accepted = 0;
     int until_resync = a.resync;
     for (int s = 0; s < a.num_sweeps; ++s) {
+        const unsigned long long accepted_before = accepted;
         bool init_now = (s == 0);
         if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
         if (init_now && active) {
@@ -337,9 +382,10 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
 #pragma unroll
             for (int t = 0; t < NT; ++t) f[t >> 1][t & 1] = fs[t];
         }
-        if (s == 0) {
+        if (stream) {
             // everything above used ordinary loads; from here on only LDS-DMA is in the VM queue
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            issued = 0; processed = 0; issue_row = 0; issue_slot = 0; cur_slot = 0;
 #pragma unroll 1
             for (int u = 0; u < C::U - 1; ++u) issue_unit();
         }
@@ -360,6 +406,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
                 if (ln >= left || !active || (a.debug & 2)) thr = -INFINITY;
                 float sg = ((xb >> t) & 1ull) ? -1.0f : 1.0f;
                 uint64_t todo = ~0ull;
+                if (stream) {
 #pragma unroll 1
                 for (int j = 0; j < 64 / GR; ++j) {
                     // retire unit (this wave's pieces), rendezvous, refill the slot just vacated
@@ -390,9 +437,32 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
                     cur_slot = uni((cur_slot + 1 == C::U) ? 0 : cur_slot + 1);
                     processed = uni(processed + 1);
                 }
+                } else {
+                    // on-demand: the plain lowest-accepting-lane loop over the whole slot (as K1)
+                    while (true) {
+                        const uint64_t m = __ballot(sg * f[t >> 1][t & 1] < thr) & todo;
+                        if (m == 0) break;
+                        const int l = __ffsll((unsigned long long)m) - 1;
+                        todo = (~0ull << l) << 1;
+                        const float sl = readlane_f(sg, l);
+                        if (ln == l) { sg = -sg; xb ^= (1ull << t); }
+                        dense_add_row_pairs<NT>(f, rsrc, t * 64 + l, ln, sl);
+                        ++accepted;
+                    }
+                }
             }
         });
-        if (pace_pop) sweep_pace_arrive_wait(a.pace, xcc, pace_pop, (unsigned int)(s + 1));
+        // workgroup-wide accepted-flip count of this sweep -> mode of the next one.  Three rotating words:
+        // the word of sweep s+2 is cleared after the rendezvous of sweep s, i.e. strictly before any wave
+        // can add to it (that needs the rendezvous of sweep s+1).
+        if (lane == 0 && accepted != accepted_before)
+            atomicAdd(&flips_word[s % 3], (unsigned int)(accepted - accepted_before));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned int wg_flips = (unsigned int)__builtin_amdgcn_readfirstlane((int)flips_word[s % 3]);
+        if (threadIdx.x == 0) flips_word[(s + 2) % 3] = 0u;
+        stream = (a.ondemand_flips == 0) || (wg_flips >= (unsigned int)a.ondemand_flips);
+        if (pace_pop) sweep_pace_arrive_wait(a.pace, xcc, pace_pop, (unsigned int)(s + 1), stream);
     }
 
     if (!active) return;
@@ -453,11 +523,10 @@ template <int NT, int GR>
 int launch_dense_wg(const DenseLaunchCtx &p, DenseArgs a, hipStream_t st)
 {
     if constexpr (WgCfg<NT, GR>::ok) {
-        if ((long long)a.num_sweeps * (((a.n + 63) / 64) * (64 / GR)) > 0x7fffffffLL)
-            return fail(MI_EINVAL, "num_sweeps too large for the ring unit counter");
         int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));
         const int blocks = (a.R + kWgWaves - 1) / kWgWaves;
+        a.ondemand_flips = (int)((long long)p.opt_ondemand_permille * a.n * kWgWaves / 1000);
         a.pace = nullptr;
         if (p.opt_pace && a.num_sweeps > 1 && blocks <= cus) {     // one 160 KB workgroup per CU
             HIP_TRY(hipMemsetAsync(p.d_pace, 0, kPaceWords * sizeof(unsigned int), st));

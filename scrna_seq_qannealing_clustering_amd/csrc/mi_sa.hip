@@ -110,6 +110,7 @@ struct mi_sa_problem {
     unsigned int *d_pace = nullptr;          // kPaceWords per launch chunk
     int opt_pace = 1;                        // sweep pacing on/off (speed only)
     int opt_variant = 0;                     // 0 auto, 1 wave-per-replica (K1), 2 workgroup/LDS ring (K1w)
+    int opt_ondemand_permille = 25;          // K1w: on-demand sweeps below this acceptance (per mille); 0 = always stream
     int opt_debug = 0;                       // DenseArgs::debug (diagnostic timing only; results are wrong)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
@@ -152,7 +153,7 @@ int ensure_run_buffers(mi_sa_problem *p, int R, int num_sweeps, bool need_init)
 
 int dispatch_dense(mi_sa_problem *p, const DenseArgs &a, hipStream_t st)
 {
-    DenseLaunchCtx ctx{p->device, p->opt_pace, p->opt_variant, p->opt_unit_rows, p->d_pace, &p->resident_waves};
+    DenseLaunchCtx ctx{p->device, p->opt_pace, p->opt_variant, p->opt_unit_rows, p->opt_ondemand_permille, p->d_pace, &p->resident_waves};
     switch (p->NT) {
 #define MI_CASE(N) case N: return mi_launch_dense_nt##N(ctx, a, st);
         MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16) MI_CASE(20) MI_CASE(24) MI_CASE(28)
@@ -368,6 +369,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
 {
     if (!p || !key) return fail(MI_EINVAL, "NULL argument");
     if (!strcmp(key, "pace")) { p->opt_pace = value != 0; return MI_OK; }
+    if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "debug")) { p->opt_debug = (int)value; return MI_OK; }
     if (!strcmp(key, "variant") && value >= 0 && value <= 2) { p->opt_variant = (int)value; return MI_OK; }
     if (!strcmp(key, "unit_rows") && (value == 0 || value == 2 || value == 4)) { p->opt_unit_rows = (int)value; return MI_OK; }
@@ -411,7 +413,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         a.states = (uint8_t *)p->d_states; a.energy = p->d_energy; a.stats = p->d_stats; a.pace = nullptr;
         a.offset = p->offset; a.n = p->n; a.R = R; a.num_sweeps = num_sweeps; a.resync = resync_interval;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-        a.debug = p->opt_debug; a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
+        a.debug = p->opt_debug; a.ondemand_flips = 0; a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
         rc = dispatch_dense(p, a, p->stream);
         if (rc) return rc;

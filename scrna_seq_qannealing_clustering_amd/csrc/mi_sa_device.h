@@ -146,11 +146,15 @@ __device__ __forceinline__ unsigned int sweep_pace_begin(unsigned int *pace, uns
     return pace_load(&pace[32 * (1 + xcc)]);
 }
 
+// every participant ARRIVES every sweep (keeps the counter meaningful); only those that are about to
+// stream Q again also WAIT for the others
 __device__ __forceinline__ void sweep_pace_arrive_wait(unsigned int *pace, unsigned int xcc,
-                                                       unsigned int pop, unsigned int sweeps_done)
+                                                       unsigned int pop, unsigned int sweeps_done,
+                                                       bool wait = true)
 {
     unsigned int *arr = &pace[32 * (1 + xcc) + 1];
     if ((threadIdx.x & 63) == 0) atomicAdd(arr, 1u);
+    if (!wait) return;
     const unsigned int target = pop * sweeps_done;
     const long long t0 = pace_clock();
     while (pace_load(arr) < target) {
@@ -179,6 +183,7 @@ struct DenseArgs {
     uint32_t replica_offset, seed_lo, seed_hi;
     uint32_t sweep_offset;  // added to the sweep index in the RNG counter (continuation of an earlier run)
     int temps_per_replica;  // 0: temps[s] per sweep; 1: temps[r], one constant temperature per replica
+    int ondemand_flips;     // K1w: sweeps whose predecessor had fewer accepted flips per workgroup run on demand (0 = never)
     int debug;              // diagnostic timing builds only: bit0 = skip LDS-DMA, bit1 = accept nothing
 };
 
@@ -215,7 +220,7 @@ int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, dou
 // what a per-NT launcher needs to know about the problem handle
 struct DenseLaunchCtx {
     int device;
-    int opt_pace, opt_variant, opt_unit_rows;
+    int opt_pace, opt_variant, opt_unit_rows, opt_ondemand_permille;
     unsigned int *d_pace;          // kMaxChunks * kPaceWords words
     int *resident_waves;           // cached occupancy of the wave-per-replica kernel (0 = unknown)
 };
