@@ -110,7 +110,7 @@ struct mi_sa_problem {
     unsigned int *d_pace = nullptr;          // kPaceWords per launch chunk
     int opt_pace = 1;                        // sweep pacing on/off (speed only)
     int opt_variant = 0;                     // 0 auto, 1 wave-per-replica (K1), 2 workgroup/LDS ring (K1w)
-    int opt_ondemand_permille = 25;          // K1w: on-demand sweeps below this acceptance (per mille); 0 = always stream
+    int opt_ondemand_permille = 40;          // K1w: on-demand sweeps below this acceptance (per mille); 0 = always stream
     int opt_debug = 0;                       // DenseArgs::debug (diagnostic timing only; results are wrong)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
