@@ -129,10 +129,10 @@ __global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
     const unsigned int pace_pop = sweep_pace_begin(a.pace, (unsigned int)a.R, xcc);
 
     unsigned long long accepted = 0;
-    int until_resync = a.resync;
+    int until_resync = a.resync_first;           // counts down at the START of a sweep
     for (int s = 0; s < a.num_sweeps; ++s) {
         bool init_now = (s == 0);
-        if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
+        if (a.resync > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
         if (init_now) dense_field_init<NT>(f, rsrc, diag_row, xb, lane);
         // temperature of this sweep as a scalar (SGPR) operand
         const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
@@ -371,16 +371,21 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
     __syncthreads();
     bool stream = true;
     unsigned long long accepted = 0;
-    int until_resync = a.resync;
+    int until_resync = a.resync_first;           // counts down at the START of a sweep
     for (int s = 0; s < a.num_sweeps; ++s) {
         const unsigned long long accepted_before = accepted;
-        bool init_now = (s == 0);
-        if (a.resync > 0 && s > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
+        bool init_now = (s == 0) && !(a.flags & kDenseFieldsIn);
+        if (a.resync > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
         if (init_now && active) {
             float fs[NT];
             dense_field_init<NT>(fs, rsrc, diag_row, xb, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t) f[t >> 1][t & 1] = fs[t];
+        } else if (s == 0 && active) {
+            // continue a run: the cached fields of the previous launch, canonical [replica][column]
+            const float *src = a.fields + (size_t)r * (NT * 64) + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) f[t >> 1][t & 1] = src[t * 64];
         }
         if (stream) {
             // everything above used ordinary loads; from here on only LDS-DMA is in the VM queue
@@ -471,11 +476,15 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
         constexpr int t = decltype(tc)::value;
         if (t * 64 + lane < n) dst[t * 64] = ((xb >> t) & 1ull) ? 1 : 0;
     });
-    const double e = dense_energy_f64<NT>(rsrc, diag_row, xb, lane);
-    if (lane == 0) {
-        a.energy[r] = e + a.offset;
-        atomicAdd(&a.stats[1], accepted);
+    if (a.flags & kDenseFieldsOut) {
+        float *out = a.fields + (size_t)r * (NT * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) out[t * 64] = f[t >> 1][t & 1];
     }
+    if (lane == 0) atomicAdd(&a.stats[1], accepted);
+    if (a.flags & kDenseNoEnergy) return;
+    const double e = dense_energy_f64<NT>(rsrc, diag_row, xb, lane);
+    if (lane == 0) a.energy[r] = e + a.offset;
 }
 
 namespace {
@@ -540,24 +549,65 @@ int launch_dense_wg(const DenseLaunchCtx &p, DenseArgs a, hipStream_t st)
     }
 }
 
+// sweeps until the first field re-synchronisation of a launch that starts at sweep s0 of its run
+inline int resync_first_for(int resync, int s0)
+{
+    return resync > 0 ? ((resync - s0 % resync) % resync) + 1 : 0;
+}
+
+template <int NT>
+int launch_dense_wg_any(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t st)
+{
+    int gr = p.opt_unit_rows ? p.opt_unit_rows : 4;       // 4 rows per rendezvous measured fastest
+    if (gr == 4 && !WgCfg<NT, 4>::ok) gr = 2;
+    switch (gr) {
+        case 2: return launch_dense_wg<NT, 2>(p, a, st);
+        case 4: return launch_dense_wg<NT, 4>(p, a, st);
+    }
+    return fail(MI_EUNSUPPORTED, "LDS ring unit of %d rows is not built for NT=%d", gr, NT);
+}
+
+// K1w over a long schedule: the run is cut into launches of `chunk` sweeps.  State (bits in
+// DenseArgs::states, cached fields in DenseArgs::fields) persists in HBM between launches, so the cut
+// points are invisible to the chain -- results are bit-identical to one launch -- and each launch can
+// be served by whichever kernel suits the acceptance rate the run has reached.
+template <int NT>
+int launch_dense_chunked(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t st)
+{
+    const int chunk = p.opt_chunk_sweeps;
+    if (chunk <= 0 || a.num_sweeps <= chunk || !p.d_fields) {
+        DenseArgs b = a;
+        b.fields = nullptr; b.ctrl = nullptr; b.flags = 0; b.my_mode = 0;
+        b.resync_first = resync_first_for(a.resync, 0);
+        return launch_dense_wg_any<NT>(p, b, st);
+    }
+    for (int s0 = 0; s0 < a.num_sweeps; s0 += chunk) {
+        const bool first = (s0 == 0), last = (s0 + chunk >= a.num_sweeps);
+        DenseArgs b = a;
+        b.num_sweeps = last ? a.num_sweeps - s0 : chunk;
+        b.temps = a.temps_per_replica ? a.temps : a.temps + s0;
+        b.sweep_offset = a.sweep_offset + (uint32_t)s0;
+        b.init = first ? a.init : a.states;
+        b.fields = p.d_fields; b.ctrl = nullptr; b.my_mode = 0;
+        b.flags = (first ? 0 : kDenseFieldsIn) | (last ? 0 : (kDenseFieldsOut | kDenseNoEnergy));
+        b.resync_first = resync_first_for(a.resync, s0);
+        int rc = launch_dense_wg_any<NT>(p, b, st);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
 template <int NT>
 int launch_dense_any(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t st)
 {
     int variant = p.opt_variant;
     if (variant == 0) variant = (a.R >= 2 * kWgWaves && a.num_sweeps > 0) ? 2 : 1;
-    if (variant == 2) {
-        int gr = p.opt_unit_rows ? p.opt_unit_rows : 4;       // 4 rows per rendezvous measured fastest
-        if (gr == 4 && !WgCfg<NT, 4>::ok) gr = 2;
-        if (gr == 2 && !WgCfg<NT, 2>::ok) gr = 1;
-        switch (gr) {
-            case 2: return launch_dense_wg<NT, 2>(p, a, st);
-            case 4: return launch_dense_wg<NT, 4>(p, a, st);
-        }
-        return fail(MI_EUNSUPPORTED, "LDS ring unit of %d rows is not built for NT=%d", gr, NT);
-    }
-    return launch_dense<NT>(p, a, st);
+    if (variant == 2) return launch_dense_chunked<NT>(p, a, st);
+    DenseArgs b = a;
+    b.fields = nullptr; b.ctrl = nullptr; b.flags = 0; b.my_mode = 0;
+    b.resync_first = resync_first_for(a.resync, 0);
+    return launch_dense<NT>(p, b, st);
 }
-
 
 }  // namespace
 

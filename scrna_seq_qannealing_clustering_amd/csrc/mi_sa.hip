@@ -110,6 +110,10 @@ struct mi_sa_problem {
     unsigned int *d_pace = nullptr;          // kPaceWords per launch chunk
     int opt_pace = 1;                        // sweep pacing on/off (speed only)
     int opt_variant = 0;                     // 0 auto, 1 wave-per-replica (K1), 2 workgroup/LDS ring (K1w)
+    int opt_chunk_sweeps = 32;               // K1w/K1m: sweeps per launch of a chunked run (0 = one launch)
+    float *d_fields = nullptr;               // cached fields between the launches of a chunked run
+    unsigned int *d_ctrl = nullptr;          // kernel-scheduling words
+    int cap_fields_R = 0;
     int opt_ondemand_permille = 40;          // K1w: on-demand sweeps below this acceptance (per mille); 0 = always stream
     int opt_debug = 0;                       // DenseArgs::debug (diagnostic timing only; results are wrong)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
@@ -153,7 +157,19 @@ int ensure_run_buffers(mi_sa_problem *p, int R, int num_sweeps, bool need_init)
 
 int dispatch_dense(mi_sa_problem *p, const DenseArgs &a, hipStream_t st)
 {
-    DenseLaunchCtx ctx{p->device, p->opt_pace, p->opt_variant, p->opt_unit_rows, p->opt_ondemand_permille, p->d_pace, &p->resident_waves};
+    if (p->opt_chunk_sweeps > 0 && a.num_sweeps > p->opt_chunk_sweeps && p->opt_variant != 1 && a.R >= 32 &&
+        (p->cap_fields_R < a.R || !p->d_fields)) {
+        if (p->d_fields) (void)hipFree(p->d_fields);
+        p->d_fields = nullptr;
+        HIP_TRY(hipMalloc((void **)&p->d_fields, (size_t)a.R * p->NT * 64 * sizeof(float)));
+        p->cap_fields_R = a.R;
+    }
+    if (!p->d_ctrl) {
+        HIP_TRY(hipMalloc((void **)&p->d_ctrl, 16 * sizeof(unsigned int)));
+        HIP_TRY(hipMemset(p->d_ctrl, 0, 16 * sizeof(unsigned int)));
+    }
+    DenseLaunchCtx ctx{p->device, p->opt_pace, p->opt_variant, p->opt_unit_rows, p->opt_ondemand_permille,
+                       p->opt_chunk_sweeps, p->d_fields, p->d_ctrl, p->d_pace, &p->resident_waves};
     switch (p->NT) {
 #define MI_CASE(N) case N: return mi_launch_dense_nt##N(ctx, a, st);
         MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16) MI_CASE(20) MI_CASE(24) MI_CASE(28)
@@ -335,7 +351,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -369,6 +385,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
 {
     if (!p || !key) return fail(MI_EINVAL, "NULL argument");
     if (!strcmp(key, "pace")) { p->opt_pace = value != 0; return MI_OK; }
+    if (!strcmp(key, "chunk_sweeps") && value >= 0) { p->opt_chunk_sweeps = (int)value; return MI_OK; }
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "debug")) { p->opt_debug = (int)value; return MI_OK; }
     if (!strcmp(key, "variant") && value >= 0 && value <= 2) { p->opt_variant = (int)value; return MI_OK; }

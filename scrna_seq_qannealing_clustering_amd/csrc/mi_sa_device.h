@@ -183,9 +183,18 @@ struct DenseArgs {
     uint32_t replica_offset, seed_lo, seed_hi;
     uint32_t sweep_offset;  // added to the sweep index in the RNG counter (continuation of an earlier run)
     int temps_per_replica;  // 0: temps[s] per sweep; 1: temps[r], one constant temperature per replica
+    float *fields;          // cached local fields between launches, canonical [R][64*NT] (nullable)
+    unsigned int *ctrl;     // kernel-scheduling words (see dense_mfma / launch_dense_chunked), nullable
+    int flags;              // kDenseFieldsIn | kDenseFieldsOut | kDenseNoEnergy
+    int resync_first;       // sweeps until the first field re-synchronisation of this launch (resync > 0)
+    int my_mode;            // value of ctrl[0] for which this kernel runs (others exit at once)
     int ondemand_flips;     // K1w: sweeps whose predecessor had fewer accepted flips per workgroup run on demand (0 = never)
     int debug;              // diagnostic timing builds only: bit0 = skip LDS-DMA, bit1 = accept nothing
 };
+
+constexpr int kDenseFieldsIn = 1;    // start from the cached fields in DenseArgs::fields (no re-initialisation)
+constexpr int kDenseFieldsOut = 2;   // leave the cached fields there at the end
+constexpr int kDenseNoEnergy = 4;    // not the last launch of a run: skip the energy epilogue
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -220,7 +229,9 @@ int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, dou
 // what a per-NT launcher needs to know about the problem handle
 struct DenseLaunchCtx {
     int device;
-    int opt_pace, opt_variant, opt_unit_rows, opt_ondemand_permille;
+    int opt_pace, opt_variant, opt_unit_rows, opt_ondemand_permille, opt_chunk_sweeps;
+    float *d_fields;               // R x 64*NT floats or nullptr
+    unsigned int *d_ctrl;
     unsigned int *d_pace;          // kMaxChunks * kPaceWords words
     int *resident_waves;           // cached occupancy of the wave-per-replica kernel (0 = unknown)
 };
