@@ -54,39 +54,6 @@ __device__ __forceinline__ void dense_field_init(float (&f)[NT], __amdgpu_buffer
     }
 }
 
-// Energy of the final state, E = sum_i x_i diag_i + 1/2 sum_{i,j} x_i x_j Q2_ij, with every fp32 matrix
-// entry added EXACTLY once into fp64 accumulators (lane l sums its own columns over all set rows; one
-// wave reduction at the end).  Independent of the cached fp32 fields, so the reported energies carry
-// no accumulated rounding of the chain.
-template <int NT>
-__device__ __forceinline__ double dense_energy_f64(__amdgpu_buffer_rsrc_t rsrc, int diag_row, uint64_t xb,
-                                                   int lane)
-{
-    constexpr int G = NT / 4;
-    const int voff = lane * 16;
-    double pair = 0.0, lin = 0.0;
-#pragma unroll 1
-    for (int t = -1; t < NT; ++t) {
-        uint64_t m = (t < 0) ? 1ull : __ballot((xb >> t) & 1ull);
-        while (m) {
-            const int l = __ffsll((unsigned long long)m) - 1;
-            m &= m - 1;
-            const int soff = ((t < 0) ? diag_row : t * 64 + l) * (NT * 256);
-            double acc = 0.0;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + g * 1024, 0);
-                acc += ((xb >> (4 * g + 0)) & 1ull) ? (double)__uint_as_float(q.x) : 0.0;
-                acc += ((xb >> (4 * g + 1)) & 1ull) ? (double)__uint_as_float(q.y) : 0.0;
-                acc += ((xb >> (4 * g + 2)) & 1ull) ? (double)__uint_as_float(q.z) : 0.0;
-                acc += ((xb >> (4 * g + 3)) & 1ull) ? (double)__uint_as_float(q.w) : 0.0;
-            }
-            if (t < 0) lin = acc; else pair += acc;
-        }
-    }
-    return wave_sum_f64(lin + 0.5 * pair);
-}
-
 template <int NT>
 __global__ void __launch_bounds__(256, 4) k_anneal_dense(DenseArgs a)
 {
@@ -291,6 +258,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
 {
     using C = WgCfg<NT, GR>;
     __shared__ __attribute__((aligned(16))) char ring[C::U * C::UNITB + 256];
+    if (!sched_my_turn(a)) return;               // a chunk that the other dense kernel serves
     // last 256 bytes: three rotating words counting the workgroup's accepted flips per sweep
     unsigned int *flips_word = reinterpret_cast<unsigned int *>(ring + C::U * C::UNITB);
 
@@ -367,7 +335,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
     // Chosen per sweep from the workgroup's accepted-flip count of the previous sweep: a geometric
     // schedule spends most of its sweeps cold (acceptance << 1 %), where streaming 30 MB per sweep per
     // workgroup to serve a handful of flips is all overhead.  Results do not depend on the mode.
-    if (threadIdx.x < 3) flips_word[threadIdx.x] = 0u;
+    if (threadIdx.x < 4) flips_word[threadIdx.x] = 0u;     // [0..2] per-sweep counts, [3] whole launch
     __syncthreads();
     bool stream = true;
     unsigned long long accepted = 0;
@@ -470,21 +438,31 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_wg(DenseArgs a)
         if (pace_pop) sweep_pace_arrive_wait(a.pace, xcc, pace_pop, (unsigned int)(s + 1), stream);
     }
 
-    if (!active) return;
-    uint8_t *dst = a.states + (size_t)r * n + lane;
-    static_for<0, NT>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        if (t * 64 + lane < n) dst[t * 64] = ((xb >> t) & 1ull) ? 1 : 0;
-    });
-    if (a.flags & kDenseFieldsOut) {
-        float *out = a.fields + (size_t)r * (NT * 64) + lane;
+    if (active) {
+        uint8_t *dst = a.states + (size_t)r * n + lane;
+        static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if (t * 64 + lane < n) dst[t * 64] = ((xb >> t) & 1ull) ? 1 : 0;
+        });
+        if (a.flags & kDenseFieldsOut) {
+            float *out = a.fields + (size_t)r * (NT * 64) + lane;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) out[t * 64] = f[t >> 1][t & 1];
+            for (int t = 0; t < NT; ++t) out[t * 64] = f[t >> 1][t & 1];
+        }
+        if (lane == 0) {
+            atomicAdd(&a.stats[1], accepted);
+            atomicAdd(&flips_word[3], (unsigned int)accepted);
+        }
+        if (!(a.flags & kDenseNoEnergy)) {
+            const double e = dense_energy_f64<NT>(rsrc, diag_row, xb, lane);
+            if (lane == 0) a.energy[r] = e + a.offset;
+        }
     }
-    if (lane == 0) atomicAdd(&a.stats[1], accepted);
-    if (a.flags & kDenseNoEnergy) return;
-    const double e = dense_energy_f64<NT>(rsrc, diag_row, xb, lane);
-    if (lane == 0) a.energy[r] = e + a.offset;
+    if (a.ctrl) {                                // wave-uniform: pick the kernel of the next chunk
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (threadIdx.x == 0) sched_finish(a, flips_word[3]);
+    }
 }
 
 namespace {
@@ -572,26 +550,72 @@ int launch_dense_wg_any(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t
 // points are invisible to the chain -- results are bit-identical to one launch -- and each launch can
 // be served by whichever kernel suits the acceptance rate the run has reached.
 template <int NT>
-int launch_dense_chunked(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t st)
+int launch_dense_mfma(const DenseArgs &a, hipStream_t st)
+{
+#if MI_NT <= 44
+#define MI_CAT2(x, y) x##y
+#define MI_CAT(x, y) MI_CAT2(x, y)
+    return MI_CAT(mi_launch_dense_mfma_nt, MI_NT)(a, st);
+#undef MI_CAT
+#undef MI_CAT2
+#else
+    (void)a; (void)st;
+    return fail(MI_EUNSUPPORTED, "K1m is not built for NT=%d (n > %d)", NT, kMaxMfmaNT * 64);
+#endif
+}
+
+template <int NT>
+int launch_dense_chunked(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t st, int variant)
 {
     const int chunk = p.opt_chunk_sweeps;
+    // variant 4 = scheduled: every chunk is offered to both kernels, the device-side mode word decides
+    const bool scheduled = (variant == 4);
+    if (variant == 3 && (chunk <= 0 || a.num_sweeps <= chunk || !p.d_fields)) {
+        DenseArgs b = a;
+        b.fields = nullptr; b.ctrl = nullptr; b.flags = 0; b.my_mode = 0; b.mode_up_flips = 0; b.chunk_index = 0;
+        b.resync_first = resync_first_for(a.resync, 0);
+        return launch_dense_mfma<NT>(b, st);
+    }
     if (chunk <= 0 || a.num_sweeps <= chunk || !p.d_fields) {
         DenseArgs b = a;
-        b.fields = nullptr; b.ctrl = nullptr; b.flags = 0; b.my_mode = 0;
+        b.fields = nullptr; b.ctrl = nullptr; b.flags = 0; b.my_mode = 0; b.mode_up_flips = 0; b.chunk_index = 0;
         b.resync_first = resync_first_for(a.resync, 0);
-        return launch_dense_wg_any<NT>(p, b, st);
+        return launch_dense_wg_any<NT>(p, b, st);   // (variant 4 never gets here: it requires chunking)
     }
-    for (int s0 = 0; s0 < a.num_sweeps; s0 += chunk) {
-        const bool first = (s0 == 0), last = (s0 + chunk >= a.num_sweeps);
+    if (scheduled) {
+        if ((a.num_sweeps + chunk - 1) / chunk + 2 > kCtrlWords - kCtrlModes)
+            return fail(MI_EINVAL, "too many chunks for the scheduler: raise chunk_sweeps");
+        HIP_TRY(hipMemsetAsync(p.d_ctrl, 0, kCtrlWords * sizeof(unsigned int), st));
+        const unsigned int start = kModeMfma;            // start hot; a short first chunk calibrates
+        HIP_TRY(hipMemcpyAsync(p.d_ctrl + kCtrlModes, &start, sizeof start, hipMemcpyHostToDevice, st));
+    }
+    int chunk_index = 0;
+    const int first_len = scheduled ? (chunk < 8 ? chunk : 8) : chunk;
+    for (int s0 = 0, len = first_len; s0 < a.num_sweeps; s0 += len, len = chunk) {
+        const bool first = (s0 == 0), last = (s0 + len >= a.num_sweeps);
         DenseArgs b = a;
-        b.num_sweeps = last ? a.num_sweeps - s0 : chunk;
+        b.num_sweeps = last ? a.num_sweeps - s0 : len;
         b.temps = a.temps_per_replica ? a.temps : a.temps + s0;
         b.sweep_offset = a.sweep_offset + (uint32_t)s0;
         b.init = first ? a.init : a.states;
-        b.fields = p.d_fields; b.ctrl = nullptr; b.my_mode = 0;
+        b.fields = p.d_fields; b.ctrl = nullptr; b.my_mode = 0; b.mode_up_flips = 0;
         b.flags = (first ? 0 : kDenseFieldsIn) | (last ? 0 : (kDenseFieldsOut | kDenseNoEnergy));
         b.resync_first = resync_first_for(a.resync, s0);
-        int rc = launch_dense_wg_any<NT>(p, b, st);
+        b.chunk_index = chunk_index++;
+        int rc;
+        if (scheduled) {
+            // next chunk goes to K1m when this one accepted at least opt_mfma_permille of its proposals
+            b.ctrl = p.d_ctrl;
+            b.mode_up_flips = (unsigned int)((double)p.opt_mfma_permille * 1e-3 * (double)a.R * a.n * b.num_sweeps);
+            if (b.mode_up_flips == 0) b.mode_up_flips = 1;
+            b.my_mode = (int)kModeMfma;
+            rc = launch_dense_mfma<NT>(b, st);
+            if (rc) return rc;
+            b.my_mode = (int)kModeWg;
+            rc = launch_dense_wg_any<NT>(p, b, st);
+        } else {
+            rc = (variant == 3) ? launch_dense_mfma<NT>(b, st) : launch_dense_wg_any<NT>(p, b, st);
+        }
         if (rc) return rc;
     }
     return MI_OK;
@@ -601,10 +625,16 @@ template <int NT>
 int launch_dense_any(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t st)
 {
     int variant = p.opt_variant;
-    if (variant == 0) variant = (a.R >= 2 * kWgWaves && a.num_sweeps > 0) ? 2 : 1;
-    if (variant == 2) return launch_dense_chunked<NT>(p, a, st);
+    if (variant == 0) {
+        variant = (a.R >= 2 * kWgWaves && a.num_sweeps > 0) ? 2 : 1;
+        // long schedules on sizes K1m is built for: let the device alternate K1m (hot) and K1w (cold)
+        if (variant == 2 && NT <= kMaxMfmaNT && a.Qm && p.d_fields && p.opt_chunk_sweeps > 0 &&
+            a.num_sweeps > p.opt_chunk_sweeps && p.opt_mfma_permille > 0)
+            variant = 4;
+    }
+    if (variant >= 2) return launch_dense_chunked<NT>(p, a, st, variant);
     DenseArgs b = a;
-    b.fields = nullptr; b.ctrl = nullptr; b.flags = 0; b.my_mode = 0;
+    b.fields = nullptr; b.ctrl = nullptr; b.flags = 0; b.my_mode = 0; b.mode_up_flips = 0; b.chunk_index = 0;
     b.resync_first = resync_first_for(a.resync, 0);
     return launch_dense<NT>(p, b, st);
 }

@@ -91,6 +91,7 @@ struct mi_sa_problem {
     // dense
     int NT = 0;
     float *d_Qp = nullptr;
+    float *d_Qm = nullptr;       // K1m: plain row-major Q2 + diagonal row (NT <= 44)
     float *d_Qs = nullptr;       // plain row-major copy (energy kernel), allocated lazily
     // structured kinds (slot-ELL)
     int slots = 0, D = 0;
@@ -109,7 +110,9 @@ struct mi_sa_problem {
     unsigned long long *d_stats = nullptr;   // 4 words: proposals, accepted, bytes, best-key
     unsigned int *d_pace = nullptr;          // kPaceWords per launch chunk
     int opt_pace = 1;                        // sweep pacing on/off (speed only)
-    int opt_variant = 0;                     // 0 auto, 1 wave-per-replica (K1), 2 workgroup/LDS ring (K1w)
+    int opt_variant = 0;                     // 0 auto, 1 wave-per-replica (K1), 2 workgroup/LDS ring (K1w), 3 MFMA (K1m)
+    int opt_mfma_permille = 0;               // (K1m is not yet faster than K1w: scheduling is opt-in)
+
     int opt_chunk_sweeps = 32;               // K1w/K1m: sweeps per launch of a chunked run (0 = one launch)
     float *d_fields = nullptr;               // cached fields between the launches of a chunked run
     unsigned int *d_ctrl = nullptr;          // kernel-scheduling words
@@ -165,11 +168,11 @@ int dispatch_dense(mi_sa_problem *p, const DenseArgs &a, hipStream_t st)
         p->cap_fields_R = a.R;
     }
     if (!p->d_ctrl) {
-        HIP_TRY(hipMalloc((void **)&p->d_ctrl, 16 * sizeof(unsigned int)));
-        HIP_TRY(hipMemset(p->d_ctrl, 0, 16 * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc((void **)&p->d_ctrl, kCtrlWords * sizeof(unsigned int)));
+        HIP_TRY(hipMemset(p->d_ctrl, 0, kCtrlWords * sizeof(unsigned int)));
     }
     DenseLaunchCtx ctx{p->device, p->opt_pace, p->opt_variant, p->opt_unit_rows, p->opt_ondemand_permille,
-                       p->opt_chunk_sweeps, p->d_fields, p->d_ctrl, p->d_pace, &p->resident_waves};
+                       p->opt_chunk_sweeps, p->opt_mfma_permille, p->d_fields, p->d_ctrl, p->d_pace, &p->resident_waves};
     switch (p->NT) {
 #define MI_CASE(N) case N: return mi_launch_dense_nt##N(ctx, a, st);
         MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16) MI_CASE(20) MI_CASE(24) MI_CASE(28)
@@ -257,6 +260,19 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
     rc = [&]() -> int {
         HIP_TRY(hipMalloc((void **)&p->d_Qp, hp.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(p->d_Qp, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (p->NT <= kMaxMfmaNT) {
+            // K1m layout: plain row-major Q2 (zero diagonal), NPAD = 64*NT columns, NPAD rows + the diagonal row
+            const size_t npad = (size_t)p->NT * 64;
+            std::vector<float> hm((npad + 1) * npad, 0.0f);
+            for (int i = 0; i < n; ++i) {
+                const float *row = Qs + (size_t)i * n;
+                float *dst = hm.data() + (size_t)i * npad;
+                for (int j = 0; j < n; ++j) dst[j] = (j == i) ? 0.0f : row[j] + row[j];
+                hm[npad * npad + i] = row[i];
+            }
+            HIP_TRY(hipMalloc((void **)&p->d_Qm, hm.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(p->d_Qm, hm.data(), hm.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         return MI_OK;
     }();
     if (rc) { mi_sa_problem_destroy(p); return rc; }
@@ -351,7 +367,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -385,10 +401,11 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
 {
     if (!p || !key) return fail(MI_EINVAL, "NULL argument");
     if (!strcmp(key, "pace")) { p->opt_pace = value != 0; return MI_OK; }
+    if (!strcmp(key, "mfma_permille") && value >= 0 && value <= 1000) { p->opt_mfma_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "chunk_sweeps") && value >= 0) { p->opt_chunk_sweeps = (int)value; return MI_OK; }
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "debug")) { p->opt_debug = (int)value; return MI_OK; }
-    if (!strcmp(key, "variant") && value >= 0 && value <= 2) { p->opt_variant = (int)value; return MI_OK; }
+    if (!strcmp(key, "variant") && value >= 0 && value <= 4) { p->opt_variant = (int)value; return MI_OK; }
     if (!strcmp(key, "unit_rows") && (value == 0 || value == 2 || value == 4)) { p->opt_unit_rows = (int)value; return MI_OK; }
     return fail(MI_EINVAL, "unknown option '%s'", key);
 }
@@ -425,7 +442,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
 
     if (p->kind == MI_KIND_DENSE) {
         DenseArgs a;
-        a.Qp = p->d_Qp; a.temps = p->d_temps;
+        a.Qp = p->d_Qp; a.Qm = p->d_Qm; a.temps = p->d_temps;
         a.init = cont ? (const uint8_t *)p->d_states : (init ? (const uint8_t *)p->d_init : nullptr);
         a.states = (uint8_t *)p->d_states; a.energy = p->d_energy; a.stats = p->d_stats; a.pace = nullptr;
         a.offset = p->offset; a.n = p->n; a.R = R; a.num_sweeps = num_sweeps; a.resync = resync_interval;

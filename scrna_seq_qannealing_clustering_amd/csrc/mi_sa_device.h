@@ -172,6 +172,8 @@ __device__ __forceinline__ void sweep_pace_arrive_wait(unsigned int *pace, unsig
 struct DenseArgs {
     const float *Qp;        // slot-permuted Q2: row i, float4 index (g*64 + lane) holds columns
                             // 64*(4g+c)+lane, c = 0..3 ; row stride = NT*64 floats; row n = diagonal
+    const float *Qm;        // K1m: plain row-major Q2 (zero diagonal), 64*NT floats per row, rows 0..64*NT-1
+                            // (zero past n) and the diagonal as row 64*NT; nullptr when not uploaded
     const float *temps;     // num_sweeps floats
     const uint8_t *init;    // nullable, R x n
     uint8_t *states;        // R x n
@@ -187,7 +189,9 @@ struct DenseArgs {
     unsigned int *ctrl;     // kernel-scheduling words (see dense_mfma / launch_dense_chunked), nullable
     int flags;              // kDenseFieldsIn | kDenseFieldsOut | kDenseNoEnergy
     int resync_first;       // sweeps until the first field re-synchronisation of this launch (resync > 0)
-    int my_mode;            // value of ctrl[0] for which this kernel runs (others exit at once)
+    int my_mode;            // mode value for which this kernel serves its chunk (otherwise it exits at once)
+    int chunk_index;        // position of this launch in its run: its mode word is ctrl[kCtrlModes + chunk_index]
+    unsigned int mode_up_flips;   // launch-wide accepted flips at or above which the NEXT launch uses K1m
     int ondemand_flips;     // K1w: sweeps whose predecessor had fewer accepted flips per workgroup run on demand (0 = never)
     int debug;              // diagnostic timing builds only: bit0 = skip LDS-DMA, bit1 = accept nothing
 };
@@ -226,10 +230,87 @@ int mi_launch_potts(const EllArgs &, hipStream_t);
 int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, double offset, double *dE,
                            uint8_t *dXt, int path, hipStream_t st);
 
+// Energy of the final state, E = sum_i x_i diag_i + 1/2 sum_{i,j} x_i x_j Q2_ij, with every fp32 matrix
+// entry added EXACTLY once into fp64 accumulators (lane l sums its own columns over all set rows; one
+// wave reduction at the end).  Independent of the cached fp32 fields, so the reported energies carry
+// no accumulated rounding of the chain.
+template <int NT>
+__device__ __forceinline__ double dense_energy_f64(__amdgpu_buffer_rsrc_t rsrc, int diag_row, uint64_t xb,
+                                                   int lane)
+{
+    constexpr int G = NT / 4;
+    const int voff = lane * 16;
+    double pair = 0.0, lin = 0.0;
+#pragma unroll 1
+    for (int t = -1; t < NT; ++t) {
+        uint64_t m = (t < 0) ? 1ull : __ballot((xb >> t) & 1ull);
+        while (m) {
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const int soff = ((t < 0) ? diag_row : t * 64 + l) * (NT * 256);
+            double acc = 0.0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + g * 1024, 0);
+                acc += ((xb >> (4 * g + 0)) & 1ull) ? (double)__uint_as_float(q.x) : 0.0;
+                acc += ((xb >> (4 * g + 1)) & 1ull) ? (double)__uint_as_float(q.y) : 0.0;
+                acc += ((xb >> (4 * g + 2)) & 1ull) ? (double)__uint_as_float(q.z) : 0.0;
+                acc += ((xb >> (4 * g + 3)) & 1ull) ? (double)__uint_as_float(q.w) : 0.0;
+            }
+            if (t < 0) lin = acc; else pair += acc;
+        }
+    }
+    return wave_sum_f64(lin + 0.5 * pair);
+}
+
+// ---- kernel scheduling across the launches of a chunked run ------------------------------------------
+// ctrl[kCtrlModes + c] = kernel that serves chunk c (kModeWg / kModeMfma), ctrl[1] = workgroups finished,
+// ctrl[2] = flips accepted by the running launch, ctrl[4], ctrl[5] = chunks served by each kernel.  For every
+// chunk BOTH kernels are enqueued; the one whose mode is not set exits at once.  The last workgroup of the
+// kernel that did run picks the mode of the NEXT chunk from the acceptance the run has reached (a word per
+// chunk, so the second kernel of the same chunk cannot see the update).  Results do not depend on the
+// choice: same chain, same state.
+constexpr unsigned int kModeWg = 0, kModeMfma = 1;
+constexpr int kCtrlModes = 8, kCtrlWords = 4096;
+
+__device__ __forceinline__ bool sched_my_turn(const DenseArgs &a)
+{
+    if (!a.ctrl) return true;
+    return (unsigned int)__builtin_amdgcn_readfirstlane(
+               (int)__hip_atomic_load(a.ctrl + kCtrlModes + a.chunk_index, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT)) == (unsigned int)a.my_mode;
+}
+
+// called by ONE thread per workgroup after the workgroup's results are stored; wg_flips = its accepted flips
+__device__ __forceinline__ void sched_finish(const DenseArgs &a, unsigned int wg_flips)
+{
+    if (!a.ctrl) return;
+    atomicAdd(&a.ctrl[2], wg_flips);
+    __threadfence();
+    const unsigned int ticket = atomicAdd(&a.ctrl[1], 1u);
+    if (ticket == gridDim.x - 1) {
+        __threadfence();
+        const unsigned int total = __hip_atomic_load(&a.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int next = (a.mode_up_flips != 0 && total >= a.mode_up_flips) ? kModeMfma : kModeWg;
+        __hip_atomic_store(&a.ctrl[kCtrlModes + a.chunk_index + 1], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.ctrl[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&a.ctrl[4 + a.my_mode], 1u);          // diagnostics: launches served by each kernel
+    }
+}
+
+// one translation unit per NT (dense_mfma_kernels.hip) for the sizes whose LDS plan fits (NT <= 44)
+#define MI_DECLARE_MFMA(N) int mi_launch_dense_mfma_nt##N(const DenseArgs &, hipStream_t);
+MI_DECLARE_MFMA(4) MI_DECLARE_MFMA(8) MI_DECLARE_MFMA(12) MI_DECLARE_MFMA(16) MI_DECLARE_MFMA(20)
+MI_DECLARE_MFMA(24) MI_DECLARE_MFMA(28) MI_DECLARE_MFMA(32) MI_DECLARE_MFMA(36) MI_DECLARE_MFMA(40)
+MI_DECLARE_MFMA(44)
+#undef MI_DECLARE_MFMA
+constexpr int kMaxMfmaNT = 44;
+
 // what a per-NT launcher needs to know about the problem handle
 struct DenseLaunchCtx {
     int device;
-    int opt_pace, opt_variant, opt_unit_rows, opt_ondemand_permille, opt_chunk_sweeps;
+    int opt_pace, opt_variant, opt_unit_rows, opt_ondemand_permille, opt_chunk_sweeps, opt_mfma_permille;
     float *d_fields;               // R x 64*NT floats or nullptr
     unsigned int *d_ctrl;
     unsigned int *d_pace;          // kMaxChunks * kPaceWords words

@@ -63,12 +63,13 @@ def test_trajectory_parity_ragged_sizes(n):
     assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-9)
 
 
-@pytest.mark.parametrize("variant,unit_rows", [(1, 0), (2, 2), (2, 4)])
+@pytest.mark.parametrize("variant,unit_rows", [(1, 0), (2, 2), (2, 4), (3, 0)])
 @pytest.mark.parametrize("n,R", [(1, 3), (64, 16), (65, 37), (300, 33), (1000, 20), (2638, 18)])
 def test_both_kernels_follow_the_same_chain(variant, unit_rows, n, R):
-    """K1 (wave per replica) and K1w (16-replica workgroup, LDS ring; ragged last workgroup) are the same
-    Markov chain: identical states to the oracle for every (size, replica count), with initial states,
-    field re-synchronisation and a replica offset in play."""
+    """K1 (wave per replica), K1w (16-replica workgroup, LDS ring; ragged last workgroup) and K1m (fields
+    as MFMA accumulators, row updates on the matrix cores) are the same Markov chain: identical states to
+    the oracle for every (size, replica count), with initial states, field re-synchronisation and a
+    replica offset in play."""
     Qs = random_sym(n, seed=1000 + n)
     betas = np.geomspace(0.05, 4.0, 9)
     init = np.random.RandomState(n).randint(0, 2, size=(R, n)).astype(np.uint8)
@@ -82,6 +83,28 @@ def test_both_kernels_follow_the_same_chain(variant, unit_rows, n, R):
         p.anneal(R, betas, 7, replica_offset=5, initial_states=init, resync_interval=4)
         st2, _, _ = p.fetch()
     assert np.array_equal(st, ost) and np.array_equal(st2, ost)
+    assert info["accepted"] == int(ostats[1])
+    assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("chunk", [3, 5])
+def test_chunked_and_scheduled_runs_equal_one_launch(variant, chunk):
+    """A run cut into launches of `chunk` sweeps -- served by K1w, by K1m, or by whichever the device-side
+    scheduler picks per chunk (variant 4) -- leaves bits AND cached fields in HBM between launches, so it is
+    the same chain as one launch: equal to the oracle, including mid-run re-synchronisation points that
+    do not coincide with the cuts."""
+    n, R = 700, 50
+    Qs = random_sym(n, seed=77)
+    betas = np.geomspace(0.02, 30.0, 23)                      # hot -> cold: the scheduler switches kernels
+    ost, oen, ostats = so.sa_dense_philox(Qs, R, betas, 3, replica_offset=1, resync_interval=7)
+    with Problem.dense(Qs) as p:
+        p.set_option("variant", variant)
+        p.set_option("chunk_sweeps", chunk)
+        p.set_option("mfma_permille", 150)
+        p.anneal(R, betas, 3, replica_offset=1, resync_interval=7)
+        st, en, info = p.fetch()
+    assert np.array_equal(st, ost)
     assert info["accepted"] == int(ostats[1])
     assert np.allclose(en, oen, rtol=E_RTOL, atol=1e-9)
 
