@@ -72,16 +72,17 @@ def cpu_baseline(Qs, betas, seconds_target=15.0):
     }
 
 
-def pmc_traffic(replicas, sweeps):
+def pmc_traffic(replicas, sweeps, launches):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload
     (profiles/r01_pmc_traffic.json, written by scripts/pmc_traffic.py on the GPU box: FETCH_SIZE doubled
-    per the gfx950 note + WRITE_SIZE).  None when no profile matches this launch shape."""
+    per the gfx950 note + WRITE_SIZE, averaged over the launches of one step).  None when no profile matches
+    this launch shape."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if rec.get("replicas") == replicas and rec.get("sweeps") == sweeps:
+    if rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("launches") == launches:
         return float(rec["hbm_bytes_per_launch"])
     return None
 
@@ -173,6 +174,7 @@ def main():
     for i in range(args.steps):
         best = step(args.warmup + i)
         kernel_ms.append(prob.kernel_ms())                         # HIP events on the engine's stream
+    launches = prob.launch_count()                                 # a long schedule is served by several launches
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -183,9 +185,11 @@ def main():
     _, en, info = prob.fetch()
     updates_per_step = world * R * len(betas) * n
     value = updates_per_step * args.steps / elapsed
-    k_ms = float(np.mean(kernel_ms))
-    alg_bytes = 4.0 * n * R * len(betas) * n                       # per launch (one GPU)
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    k_ms = float(np.mean(kernel_ms))                               # all launches of one step
+    launch_ms = k_ms / launches                                    # = rocprofv3's average duration of the kernel
+    sweeps_per_launch = len(betas) / launches
+    alg_bytes = 4.0 * n * R * sweeps_per_launch * n                # per launch (one GPU)
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
     row_bytes = info["accepted"] * (((n + 255) // 256) * 256 * 4)  # padded row actually requested
     best_state = best[3]
     cut_edges = int(np.sum(best_state[eu] != best_state[ev]))
@@ -199,9 +203,12 @@ def main():
                                "geometric beta, seed 1234" % (R, len(betas)),
                    "n": n, "replicas_per_gpu": R, "sweeps": int(len(betas)), "parallelism": "replicas sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(R, len(betas)),
-                     "kernel": "k_anneal_dense_wg<44,4>", "kernel_ms": k_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(R, len(betas), launches),
+                     "kernel": "k_anneal_dense_wg<44,4>", "kernel_ms": launch_ms,
+                     "launches_per_step": launches, "sweeps_per_launch": sweeps_per_launch,
+                     "kernel_ms_per_step": k_ms,
                      "algorithmic_bytes_per_update": 4 * n,
+                     "algorithmic_bytes_per_launch": alg_bytes,
                      "rows_GBps": row_bytes / (k_ms * 1e-3) / 1e9,
                      "acceptance": info["accepted"] / info["proposals"]},
         "best_energy": float(m.energies(best_state[None, :])[0]),

@@ -111,6 +111,11 @@ int mi_sa_sync(mi_sa_problem *p);
  * recorded on the problem's stream around the launch (milliseconds); implies mi_sa_sync. */
 int mi_sa_last_kernel_ms(mi_sa_problem *p, float *out_ms);
 
+/* Number of anneal-kernel launches that served the last mi_sa_anneal (long schedules are cut into launches
+ * of `chunk_sweeps` sweeps whose state persists in HBM; results do not depend on the cut).  The time of
+ * mi_sa_last_kernel_ms divided by this count is the average launch duration a profiler reports. */
+int mi_sa_last_launch_count(mi_sa_problem *p, int *out_launches);
+
 /* Copy results of the last run to host: states (R x n, uint8 or uint16 by kind; nullable),
  * energies (R doubles, recomputed from the final state on device; nullable), stats (nullable):
  * stats[0] proposals, stats[1] accepted moves, stats[2] Q/CSR bytes read by accepted moves. */

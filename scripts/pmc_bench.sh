@@ -2,7 +2,7 @@
 # rocprofv3 passes over the bench workload itself (1 step): kernel trace + stats, then FETCH_SIZE and
 # WRITE_SIZE in their own --pmc passes (never combined with trace domains).
 set -u
-out=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench
+out=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc_bench}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/trace.log 2>&1

@@ -49,6 +49,7 @@ def _declare(lib):
                                       C.c_uint32, C.c_uint32]),
         "mi_sa_sync": (C.c_int, [vp]),
         "mi_sa_last_kernel_ms": (C.c_int, [vp, f32p]),
+        "mi_sa_last_launch_count": (C.c_int, [vp, ip]),
         "mi_sa_fetch": (C.c_int, [vp, vp, f64p, u64p]),
         "mi_sa_best": (C.c_int, [vp, ip, f64p, u64p, vp]),
         "mi_sa_qubo_dense_f32": (C.c_int, [f32p, C.c_int, C.c_double, C.c_int, C.c_int, f64p,
@@ -68,7 +69,7 @@ EXPORTS = (
     "mi_last_error", "mi_abi_version", "mi_device_count", "mi_device_info",
     "mi_sa_problem_create_dense_f32", "mi_sa_problem_create_csr_rank1_f32",
     "mi_sa_problem_create_potts_csr_f32", "mi_sa_problem_destroy", "mi_sa_problem_info",
-    "mi_sa_set_option", "mi_sa_debug_pace", "mi_sa_anneal", "mi_sa_anneal_ex", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_fetch", "mi_sa_best",
+    "mi_sa_set_option", "mi_sa_debug_pace", "mi_sa_anneal", "mi_sa_anneal_ex", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_last_launch_count", "mi_sa_fetch", "mi_sa_best",
     "mi_sa_qubo_dense_f32", "mi_energy_dense_f32", "mi_energy_dense_f32_ex",
 )
 

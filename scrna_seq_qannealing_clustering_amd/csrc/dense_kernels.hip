@@ -503,6 +503,7 @@ int launch_dense(const DenseLaunchCtx &p, DenseArgs a, hipStream_t st)
         hipLaunchKernelGGL(k_anneal_dense<NT>, dim3((cnt + 3) / 4), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
     }
+    *p.launches = c;
     return MI_OK;
 }
 
@@ -618,6 +619,7 @@ int launch_dense_chunked(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_
         }
         if (rc) return rc;
     }
+    *p.launches = chunk_index;
     return MI_OK;
 }
 

@@ -121,6 +121,7 @@ struct mi_sa_problem {
     int opt_debug = 0;                       // DenseArgs::debug (diagnostic timing only; results are wrong)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
+    int last_launches = 1;                   // kernel launches that served the last anneal
     size_t state_elem = 1;
 };
 
@@ -172,7 +173,9 @@ int dispatch_dense(mi_sa_problem *p, const DenseArgs &a, hipStream_t st)
         HIP_TRY(hipMemset(p->d_ctrl, 0, kCtrlWords * sizeof(unsigned int)));
     }
     DenseLaunchCtx ctx{p->device, p->opt_pace, p->opt_variant, p->opt_unit_rows, p->opt_ondemand_permille,
-                       p->opt_chunk_sweeps, p->opt_mfma_permille, p->d_fields, p->d_ctrl, p->d_pace, &p->resident_waves};
+                       p->opt_chunk_sweeps, p->opt_mfma_permille, p->d_fields, p->d_ctrl, p->d_pace, &p->resident_waves,
+                       &p->last_launches};
+    p->last_launches = 1;
     switch (p->NT) {
 #define MI_CASE(N) case N: return mi_launch_dense_nt##N(ctx, a, st);
         MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16) MI_CASE(20) MI_CASE(24) MI_CASE(28)
@@ -466,6 +469,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
             for (size_t k = 0; k < (size_t)R * p->n; ++k)
                 if (l[k] >= (uint16_t)p->K) return fail(MI_EINVAL, "initial label %u >= K = %d", (unsigned)l[k], p->K);
         }
+        p->last_launches = 1;
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
         rc = (p->kind == MI_KIND_POTTS_CSR) ? mi_launch_potts(a, p->stream) : mi_launch_csr_rank1(a, p->stream);
         if (rc) return rc;
@@ -496,6 +500,14 @@ int mi_sa_last_kernel_ms(mi_sa_problem *p, float *out_ms)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventSynchronize(p->ev1));
     HIP_TRY(hipEventElapsedTime(out_ms, p->ev0, p->ev1));
+    return MI_OK;
+}
+
+int mi_sa_last_launch_count(mi_sa_problem *p, int *out_launches)
+{
+    if (!p || !out_launches) return fail(MI_EINVAL, "NULL argument");
+    if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
+    *out_launches = p->last_launches;
     return MI_OK;
 }
 

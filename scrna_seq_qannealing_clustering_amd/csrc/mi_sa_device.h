@@ -315,6 +315,7 @@ struct DenseLaunchCtx {
     unsigned int *d_ctrl;
     unsigned int *d_pace;          // kMaxChunks * kPaceWords words
     int *resident_waves;           // cached occupancy of the wave-per-replica kernel (0 = unknown)
+    int *launches;                 // out: kernel launches that serve this anneal (a chunked run has several)
 };
 
 constexpr int kMaxChunks = 64;

@@ -131,6 +131,12 @@ class Problem:
         _lib.check(_lib.load().mi_sa_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def launch_count(self) -> int:
+        """Kernel launches that served the last anneal (kernel_ms() / launch_count() = mean launch time)."""
+        k = C.c_int(0)
+        _lib.check(_lib.load().mi_sa_last_launch_count(self._h, C.byref(k)))
+        return int(k.value)
+
     def fetch(self, states: bool = True, energies: bool = True):
         if self._last is None:
             raise RuntimeError("fetch() before anneal()")
