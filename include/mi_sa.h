@@ -83,6 +83,10 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value);
 /* Diagnostic: copies the first `words` pacing words of the last launch (layout in mi_sa.hip). */
 int mi_sa_debug_pace(mi_sa_problem *p, unsigned int *out, int words);
 
+/* Diagnostic: copies the first `words` (<= 16) 64-bit statistics words of the last run ([0..2] as in
+ * mi_sa_fetch; [8..12] per-phase cycle sums of builds compiled with -DMI_K2_PROFILE, otherwise 0). */
+int mi_sa_debug_stats(mi_sa_problem *p, uint64_t *out, int words);
+
 /* ---- the anneal (replaces the sampler call itself) ------------------------------------------- */
 
 /* R independent Metropolis chains x num_sweeps sweeps, one beta per sweep (betas[num_sweeps]).

@@ -1,0 +1,55 @@
+/*
+ * mi_snn.h -- C ABI of the SNN-graph construction on MI355X (part of libmi_sa.so).
+ *
+ * This is the step immediately BEFORE the anneal path.  The reference does
+ * it in R, outside its Python package:
+ *     /root/reference/R/pbmc3k/Pbmc3k_prepare_data_for_QA_clustering.Rmd:67   FindNeighbors(dims = 1:dim,
+ *          k.param = k, compute.SNN = TRUE, prune.SNN = coff)     kNN (self included) + Jaccard SNN
+ *     :70-72   snn <- graphs[["SCT_snn"]] - diag(n)
+ *     :75-79   sequential, in-place, symmetric top-`ord` trim of every column (stable order())
+ *     (same loop: R/kidney/Kidney_data.Rmd:210-266, R/pbmc3k/Pbmc3k_general_data_preparation.Rmd:59-123)
+ * and hands the result to Python as a GEXF file (create_graphs.py:5-8).  mi_snn_build_f32 replaces that whole
+ * step: points in, trimmed SNN graph out (CSR of shared-neighbour COUNTS s_ij; the Jaccard weight is
+ * w_ij = s_ij / (2k - s_ij), evaluated by the caller in fp64 exactly as R does).
+ *
+ * Arithmetic (mirrored bit for bit by oracle/snn_oracle.c): exact kNN with fp32 squared distances
+ *     d(i,j) = fmaf chain over c of (x_ic - x_jc)^2,   neighbours ordered by (d, j);
+ * everything after the kNN is integer work.  Seurat's default neighbour search is approximate (annoy): an
+ * exact search is what its `nn.method = "rann", eps = 0` computes.
+ *
+ * Conventions as in mi_sa.h: plain C types, caller-allocated host arrays, 0 / negative MI_E* return codes,
+ * mi_last_error() for the message.
+ */
+#ifndef MI_SNN_H
+#define MI_SNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_snn_graph mi_snn_graph;
+
+/* X: n x dim row-major fp32 (e.g. PCA coordinates), 1 <= dim <= 64; k = k.param (the point itself counts,
+ * 2 <= k <= 64, k <= n); prune = prune.SNN (weights below it are dropped; 0 keeps everything);
+ * ord = degree cap of the trim (<= 0: no trim).  Builds the graph on `device` and keeps it in HBM. */
+int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int ord, int device,
+                     mi_snn_graph **out);
+
+/* nnz = stored (directed) entries of the final graph = 2 x edges; max_degree over its rows. */
+int mi_snn_info(const mi_snn_graph *g, int *n, int *k, int64_t *nnz, int *max_degree);
+
+/* Copy to host (each pointer nullable): nn  n x k neighbour indices (column 0 = the point itself, then
+ * ascending (distance, index)); rowptr n+1; col / shared nnz entries, rows ascending by column. */
+int mi_snn_fetch(mi_snn_graph *g, int32_t *nn, int64_t *rowptr, int32_t *col, int32_t *shared);
+
+/* Device time of the three stages of the build (HIP events), milliseconds. */
+int mi_snn_kernel_ms(const mi_snn_graph *g, float *knn_ms, float *snn_ms, float *trim_ms);
+
+int mi_snn_destroy(mi_snn_graph *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SNN_H */

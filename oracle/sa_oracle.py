@@ -11,9 +11,9 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "sa_oracle.c")
-    if force or not os.path.exists(so) or (
-            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    srcs = [os.path.join(_HERE, f) for f in ("sa_oracle.c", "snn_oracle.c")]
+    if force or not os.path.exists(so) or any(
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so) for src in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"])
     return so
 

@@ -1,0 +1,60 @@
+"""ctypes wrapper over the SNN-construction restatement in oracle/snn_oracle.c.  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+
+import numpy as np
+
+from . import sa_oracle as _so
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def knn(X, k):
+    """(n, k) int32: column 0 = the point itself, then its k-1 nearest others by (fp32 distance, index)."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    n, dim = X.shape
+    nn = np.empty((n, k), dtype=np.int32)
+    rc = _so.lib().orc_knn_f32(_p(X, C.c_float), n, dim, int(k), _p(nn, C.c_int32))
+    if rc:
+        raise ValueError("orc_knn_f32 failed (k out of range?)")
+    return nn
+
+
+def snn_rows(nn, prune=0.0):
+    """CSR (rowptr int64, col int32, shared int32) of s_ij = |N(i) & N(j)|, j != i, s/(2k-s) >= prune."""
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    n, k = nn.shape
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    lib = _so.lib()
+    lib.orc_snn_rows.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.orc_snn_rows(_p(nn, C.c_int32), n, k, float(prune), _p(rowptr, C.c_int64), None, None)
+    col = np.empty(int(rowptr[-1]), dtype=np.int32)
+    shared = np.empty(int(rowptr[-1]), dtype=np.int32)
+    lib.orc_snn_rows(_p(nn, C.c_int32), n, k, float(prune), _p(rowptr, C.c_int64), _p(col, C.c_int32),
+                     _p(shared, C.c_int32))
+    return rowptr, col, shared
+
+
+def trim(rowptr, col, shared, ord):
+    """alive mask (uint8 per stored entry) after the sequential symmetric top-`ord` trim."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    alive = np.ones(len(col), dtype=np.uint8)
+    lib = _so.lib()
+    lib.orc_snn_trim.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
+                                 C.POINTER(C.c_uint8)]
+    lib.orc_snn_trim(len(rowptr) - 1, _p(rowptr, C.c_int64), _p(np.ascontiguousarray(col, dtype=np.int32), C.c_int32),
+                     _p(np.ascontiguousarray(shared, dtype=np.int32), C.c_int32), int(ord or 0), _p(alive, C.c_uint8))
+    return alive
+
+
+def snn_graph(X, k, prune=0.0, ord=None):
+    """Whole pipeline: returns (nn, rowptr, col, shared) of the trimmed graph (rows ascending by column)."""
+    nn = knn(X, k)
+    rowptr, col, shared = snn_rows(nn, prune)
+    alive = trim(rowptr, col, shared, ord).astype(bool)
+    rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+    deg = np.bincount(rows[alive], minlength=len(rowptr) - 1)
+    out_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    return nn, out_ptr, col[alive], shared[alive]

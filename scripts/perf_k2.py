@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""A/B timing of the structured kernels on the bench graph (development helper).
+usage: perf_k2.py [--sweeps S] [--replicas R] [--n N] variant=0 variant=1 ..."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scrna_seq_qannealing_clustering_amd import graphs, models  # noqa: E402
+from scrna_seq_qannealing_clustering_amd.engine import Problem  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sweeps", type=int, default=200)
+ap.add_argument("--replicas", type=int, default=4096)
+ap.add_argument("--n", type=int, default=2638)
+ap.add_argument("--rounds", type=int, default=2)
+ap.add_argument("--check", action="store_true")
+ap.add_argument("arms", nargs="*", default=["variant=1", "variant=0"])
+a = ap.parse_args()
+nodes, eu, ev, w, _ = graphs.synthetic_snn(a.n, 5, 15, 15, 9, seed=0)
+G = graphs.EdgeListGraph(nodes, eu, ev, w)
+m = models.build_bqm_qubo(G, 0.05, k=8)
+betas = models.make_beta_schedule(a.sweeps, models.default_beta_range(m))
+ref = None
+with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
+                       float(np.float32(m.c_pair))) as p:
+    for rnd in range(a.rounds):
+        for arm in a.arms:
+            for kv in arm.split(","):
+                k, v = kv.split("=")
+                p.set_option(k, int(v))
+            p.anneal(a.replicas, betas, 1234)
+            ms = p.kernel_ms()
+            st, en, info = p.fetch()
+            ds = p.debug_stats()
+            if ds[8:13].any():
+                tot = float(ds[8:13].sum())
+                print("   phase cycles/wave/sweep: pre %.0f loop %.0f wait %.0f apply %.0f init %.0f" % tuple(
+                    float(x) / a.replicas / a.sweeps for x in ds[8:13]))
+            if a.check:
+                if ref is None:
+                    ref = st.copy()
+                assert np.array_equal(ref, st), "arm %s changed the results" % arm
+            print("round %d %-20s %9.2f ms  %.3e upd/s  acc %.3f  minE %.3f" % (
+                rnd, arm, ms, a.replicas * a.sweeps * a.n / ms * 1e3, info["accepted"] / info["proposals"], en.min()),
+                flush=True)

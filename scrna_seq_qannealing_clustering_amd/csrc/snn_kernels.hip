@@ -1,0 +1,476 @@
+// snn_kernels.hip -- SNN-graph construction on MI355X (gfx950): exact kNN -> shared-neighbour counts ->
+// prune -> zero diagonal -> sequential symmetric top-`ord` trim.  C ABI: include/mi_snn.h.
+//
+// Replaces the R step that produces the reference's input graphs
+// (/root/reference/R/pbmc3k/Pbmc3k_prepare_data_for_QA_clustering.Rmd:67-79; the GEXF file it writes is
+// what create_graphs.py:5-8 loads).  Arithmetic is fixed in oracle/snn_oracle.c and mirrored here:
+//   d(i,j) = fp32 fmaf chain over the coordinates; neighbours ordered by (d, j); the rest is integers.
+//
+// Kernels
+//   S1 k_knn<DP,KM>    one query point per thread, candidates streamed through an LDS tile that every thread
+//                      reads at the same address (broadcast), running top-KM list in registers (unrolled
+//                      compare-swap insertion).  VALU-bound: n^2 * dim fused multiply-adds.
+//   S2 k_rn_*          reverse-neighbour lists RN(m) = { j : m in N(j) } (count, scan, fill).
+//   S3 k_snn_rows<P>   one workgroup per row i, persistent: shared counts s_ij accumulated in byte counters in
+//                      LDS (one per point) by walking RN(m) for m in N(i); a second walk reads-and-clears
+//                      them (atomic AND: the first visitor of a duplicate candidate wins).  Pass 0 counts the
+//                      row, pass 1 emits it, bitonic-sorted by column.  Integer / LDS-atomic bound.
+//   S4 k_trim          ONE workgroup walks the columns in order (the reference's loop is sequential and in
+//                      place: what column i sees depends on what columns < i deleted).  Latency-bound by design.
+//   S5 k_compact_*     drops the deleted entries.
+#include <climits>
+#include <cmath>
+#include <vector>
+
+#include "../../include/mi_snn.h"
+#include "mi_sa_device.h"
+
+namespace mi_sa_impl {
+namespace {
+
+constexpr int kKnnThreads = 256;
+
+template <int DP, int KM>
+__global__ void __launch_bounds__(kKnnThreads) k_knn(const float *__restrict__ X, int n, int dim, int k,
+                                                     int32_t *__restrict__ nn)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kKnnThreads * DP];
+    const int i = blockIdx.x * kKnnThreads + threadIdx.x;
+    float xq[DP];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) xq[c] = (i < n && c < dim) ? X[(size_t)i * dim + c] : 0.0f;
+    float bd[KM];
+    int bj[KM];
+#pragma unroll
+    for (int p = 0; p < KM; ++p) { bd[p] = INFINITY; bj[p] = INT_MAX; }
+
+    for (int j0 = 0; j0 < n; j0 += kKnnThreads) {
+        __syncthreads();
+        {
+            const int j = j0 + (int)threadIdx.x;
+#pragma unroll
+            for (int c = 0; c < DP; ++c)
+                tile[threadIdx.x * DP + c] = (j < n && c < dim) ? X[(size_t)j * dim + c] : 0.0f;
+        }
+        __syncthreads();
+        const int lim = n - j0 < kKnnThreads ? n - j0 : kKnnThreads;
+        for (int jj = 0; jj < lim; ++jj) {
+            const f32x4 *tp = reinterpret_cast<const f32x4 *>(tile + jj * DP);
+            float d = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < DP / 4; ++c4) {
+                const f32x4 v = tp[c4];                   // same address in every lane: LDS broadcast
+                float df;
+                df = xq[4 * c4 + 0] - v.x; d = __fmaf_rn(df, df, d);
+                df = xq[4 * c4 + 1] - v.y; d = __fmaf_rn(df, df, d);
+                df = xq[4 * c4 + 2] - v.z; d = __fmaf_rn(df, df, d);
+                df = xq[4 * c4 + 3] - v.w; d = __fmaf_rn(df, df, d);
+            }
+            const int j = j0 + jj;
+            if (j != i && d < bd[KM - 1]) {               // candidates arrive by ascending j: equal d never displaces
+                bd[KM - 1] = d;
+                bj[KM - 1] = j;
+#pragma unroll
+                for (int p = KM - 1; p > 0; --p) {
+                    if (bd[p] < bd[p - 1]) {
+                        const float td = bd[p]; bd[p] = bd[p - 1]; bd[p - 1] = td;
+                        const int tj = bj[p]; bj[p] = bj[p - 1]; bj[p - 1] = tj;
+                    }
+                }
+            }
+        }
+    }
+    if (i < n) {
+        nn[(size_t)i * k] = i;
+#pragma unroll
+        for (int p = 0; p < KM; ++p)
+            if (p < k - 1) nn[(size_t)i * k + 1 + p] = bj[p];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rn_count(const int32_t *__restrict__ nn, long long total, int *__restrict__ cnt)
+{
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+        atomicAdd(&cnt[nn[e]], 1);
+}
+
+// out[0] = 0, out[i+1] = in[0] + .. + in[i]  (single workgroup; n up to millions is a few dozen passes)
+__global__ void __launch_bounds__(1024) k_scan_exclusive(const int *__restrict__ in, int *__restrict__ out, int n)
+{
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) { carry = 0; out[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const int v = i < n ? in[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n) out[i + 1] = carry + part[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rn_fill(const int32_t *__restrict__ nn, int n, int k,
+                                                 const int *__restrict__ rn_ptr, int *__restrict__ cursor,
+                                                 int32_t *__restrict__ rn_idx)
+{
+    const long long total = (long long)n * k;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int m = nn[e];
+        const int pos = atomicAdd(&cursor[m], 1);
+        rn_idx[rn_ptr[m] + pos] = (int32_t)(e / k);
+    }
+}
+
+constexpr int kRowCap = 4096;          // candidates a row may emit (LDS sort buffer): hubs beyond it are an error
+
+// PASS 0: deg[i] = entries of row i.  PASS 1: col/shared at rowptr[i], ascending by column.
+template <int PASS>
+__global__ void __launch_bounds__(256) k_snn_rows(const int32_t *__restrict__ nn, int n, int k, double prune,
+                                                  const int *__restrict__ rn_ptr, const int32_t *__restrict__ rn_idx,
+                                                  int *__restrict__ deg, const int *__restrict__ rowptr,
+                                                  int32_t *__restrict__ col, int32_t *__restrict__ shared,
+                                                  int *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    unsigned int *cnt32 = reinterpret_cast<unsigned int *>(lds);               // one byte per point
+    const int words = (n + 3) / 4;
+    unsigned long long *rowbuf = reinterpret_cast<unsigned long long *>(lds + (size_t)((words * 4 + 15) / 16) * 16);
+    __shared__ int nrow;
+    for (int w = threadIdx.x; w < words; w += 256) cnt32[w] = 0u;
+    if (threadIdx.x == 0) nrow = 0;
+    __syncthreads();
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        for (int p = 0; p < k; ++p) {
+            const int m = nn[(size_t)i * k + p];
+            for (int e = rn_ptr[m] + (int)threadIdx.x; e < rn_ptr[m + 1]; e += 256) {
+                const int j = rn_idx[e];
+                atomicAdd(&cnt32[j >> 2], 1u << (8 * (j & 3)));
+            }
+        }
+        __syncthreads();
+        for (int p = 0; p < k; ++p) {
+            const int m = nn[(size_t)i * k + p];
+            for (int e = rn_ptr[m] + (int)threadIdx.x; e < rn_ptr[m + 1]; e += 256) {
+                const int j = rn_idx[e];
+                const int sh = 8 * (j & 3);
+                const unsigned int old = atomicAnd(&cnt32[j >> 2], ~(0xffu << sh));
+                const int s = (int)((old >> sh) & 0xffu);
+                if (s == 0 || j == i) continue;
+                if ((double)s / (2.0 * (double)k - (double)s) < prune) continue;
+                const int idx = atomicAdd(&nrow, 1);
+                if (PASS == 1 && idx < kRowCap) rowbuf[idx] = ((unsigned long long)(unsigned int)j << 32) | (unsigned int)s;
+            }
+        }
+        __syncthreads();
+        const int cntrow = nrow;
+        if (PASS == 0) {
+            if (threadIdx.x == 0) {
+                deg[i] = cntrow;
+                if (cntrow > kRowCap) atomicExch(err, 1);
+            }
+        } else if (cntrow <= kRowCap) {
+            int m2 = 1;
+            while (m2 < cntrow) m2 <<= 1;
+            for (int e = cntrow + (int)threadIdx.x; e < m2; e += 256) rowbuf[e] = ~0ull;
+            __syncthreads();
+            for (int size = 2; size <= m2; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int e = threadIdx.x; e < m2; e += 256) {
+                        const int partner = e ^ stride;
+                        if (partner > e) {
+                            const bool up = (e & size) == 0;
+                            const unsigned long long a = rowbuf[e], b = rowbuf[partner];
+                            if ((a > b) == up) { rowbuf[e] = b; rowbuf[partner] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            const int base = rowptr[i];
+            for (int e = threadIdx.x; e < cntrow; e += 256) {
+                col[base + e] = (int32_t)(rowbuf[e] >> 32);
+                shared[base + e] = (int32_t)(rowbuf[e] & 0xffffffffull);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) nrow = 0;
+        __syncthreads();
+    }
+}
+
+// The reference's trim loop (Rmd :75-79) on the CSR form: for i = 0..n-1 in order, keep the `ord` largest
+// entries of column i (ties: lower row index first -- R's stable order()) and delete the others together
+// with their mirrors.  One workgroup, sequential over i.
+constexpr int kTrimThreads = 256;
+__global__ void __launch_bounds__(kTrimThreads) k_trim(int n, int ord, const int *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ col,
+                                                       const int32_t *__restrict__ shared, unsigned char *alive)
+{
+    __shared__ int key[kRowCap];
+    __shared__ int nalive;
+    for (int i = 0; i < n; ++i) {
+        const int base = rowptr[i], deg = rowptr[i + 1] - base;
+        if (deg <= ord) continue;                                   // uniform: nothing can be deleted here
+        if (threadIdx.x == 0) nalive = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int e = threadIdx.x; e < deg; e += kTrimThreads) {
+            const unsigned char al = __hip_atomic_load(&alive[base + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            key[e] = al ? shared[base + e] : -1;
+            mine += al ? 1 : 0;
+        }
+        if (mine) atomicAdd(&nalive, mine);
+        __syncthreads();
+        if (nalive > ord) {                                         // uniform
+            for (int e = threadIdx.x; e < deg; e += kTrimThreads) {
+                const int ke = key[e];
+                if (ke < 0) continue;
+                int rank = 0;
+                for (int f = 0; f < deg; ++f) {
+                    const int kf = key[f];
+                    rank += (kf > ke || (kf == ke && f < e)) ? 1 : 0;
+                }
+                if (rank >= ord) {
+                    __hip_atomic_store(&alive[base + e], (unsigned char)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int j = col[base + e];
+                    int lo = rowptr[j], hi = rowptr[j + 1] - 1;
+                    while (lo <= hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const int cm = col[mid];
+                        if (cm == i) {
+                            __hip_atomic_store(&alive[mid], (unsigned char)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        if (cm < i) lo = mid + 1; else hi = mid - 1;
+                    }
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_compact_count(int n, const int *__restrict__ rowptr,
+                                                       const unsigned char *__restrict__ alive, int *__restrict__ deg,
+                                                       int *__restrict__ maxdeg)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int c = 0;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) c += alive[e] ? 1 : 0;
+    deg[i] = c;
+    atomicMax(maxdeg, c);
+}
+
+__global__ void __launch_bounds__(256) k_compact_fill(int n, const int *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      const int32_t *__restrict__ shared,
+                                                      const unsigned char *__restrict__ alive,
+                                                      const int *__restrict__ out_ptr, int32_t *__restrict__ out_col,
+                                                      int32_t *__restrict__ out_shared)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int o = out_ptr[i];
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+        if (alive[e]) { out_col[o] = col[e]; out_shared[o] = shared[e]; ++o; }
+}
+
+template <int DP>
+int launch_knn(const float *dX, int n, int dim, int k, int32_t *d_nn, hipStream_t st)
+{
+    const int blocks = (n + kKnnThreads - 1) / kKnnThreads;
+    const int kk = k - 1;
+    if (kk <= 8) hipLaunchKernelGGL((k_knn<DP, 8>), dim3(blocks), dim3(kKnnThreads), 0, st, dX, n, dim, k, d_nn);
+    else if (kk <= 16) hipLaunchKernelGGL((k_knn<DP, 16>), dim3(blocks), dim3(kKnnThreads), 0, st, dX, n, dim, k, d_nn);
+    else if (kk <= 32) hipLaunchKernelGGL((k_knn<DP, 32>), dim3(blocks), dim3(kKnnThreads), 0, st, dX, n, dim, k, d_nn);
+    else hipLaunchKernelGGL((k_knn<DP, 64>), dim3(blocks), dim3(kKnnThreads), 0, st, dX, n, dim, k, d_nn);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace
+}  // namespace mi_sa_impl
+using namespace mi_sa_impl;
+
+struct mi_snn_graph {
+    int n = 0, dim = 0, k = 0, ord = 0, device = 0, max_degree = 0;
+    long long nnz = 0;
+    float ms_knn = 0, ms_snn = 0, ms_trim = 0;
+    int32_t *d_nn = nullptr;
+    int *d_ptr = nullptr;            // final rowptr (n+1)
+    int32_t *d_col = nullptr, *d_shared = nullptr;
+};
+
+extern "C" {
+
+int mi_snn_destroy(mi_snn_graph *g)
+{
+    if (!g) return MI_OK;
+    (void)hipSetDevice(g->device);
+    void *bufs[] = {g->d_nn, g->d_ptr, g->d_col, g->d_shared};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete g;
+    return MI_OK;
+}
+
+int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int ord, int device, mi_snn_graph **out)
+{
+    if (!X || !out) return fail(MI_EINVAL, "NULL argument");
+    if (n < 2 || dim < 1 || dim > 64) return fail(MI_EINVAL, "need n >= 2 and 1 <= dim <= 64 (got n=%d dim=%d)", n, dim);
+    if (k < 2 || k > 64 || k > n) return fail(MI_EINVAL, "need 2 <= k <= min(64, n) (got k=%d)", k);
+    if (!(prune >= 0.0)) return fail(MI_EINVAL, "prune must be >= 0");
+    if ((size_t)n + kRowCap * 8 + 64 > 160 * 1024)
+        return fail(MI_EUNSUPPORTED, "SNN kernel keeps one byte per point in LDS: n <= %d (got %d)", 160 * 1024 - kRowCap * 8 - 64, n);
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(MI_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= cnt) return fail(MI_EINVAL, "device %d out of range [0,%d)", device, cnt);
+    HIP_TRY(hipSetDevice(device));
+    mi_snn_graph *g = new (std::nothrow) mi_snn_graph();
+    if (!g) return fail(MI_ENOMEM, "out of host memory");
+    g->n = n; g->dim = dim; g->k = k; g->ord = ord; g->device = device;
+
+    float *dX = nullptr;
+    int *d_cnt = nullptr, *d_rn_ptr = nullptr, *d_cursor = nullptr, *d_deg = nullptr, *d_ptr0 = nullptr, *d_err = nullptr;
+    int32_t *d_rn_idx = nullptr, *d_col0 = nullptr, *d_sh0 = nullptr;
+    unsigned char *d_alive = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st = nullptr;
+    int rc = [&]() -> int {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipMalloc((void **)&dX, (size_t)n * dim * sizeof(float)));
+        HIP_TRY(hipMemcpy(dX, X, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&g->d_nn, (size_t)n * k * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&d_cnt, (size_t)(n + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&d_rn_ptr, (size_t)(n + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&d_cursor, (size_t)(n + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&d_rn_idx, (size_t)n * k * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&d_deg, (size_t)(n + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&d_ptr0, (size_t)(n + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&g->d_ptr, (size_t)(n + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&d_err, 2 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)(n + 1) * sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(d_cursor, 0, (size_t)(n + 1) * sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(d_err, 0, 2 * sizeof(int), st));
+
+        // S1: exact kNN
+        HIP_TRY(hipEventRecord(ev[0], st));
+        int r2 = dim <= 16 ? launch_knn<16>(dX, n, dim, k, g->d_nn, st)
+                           : (dim <= 32 ? launch_knn<32>(dX, n, dim, k, g->d_nn, st) : launch_knn<64>(dX, n, dim, k, g->d_nn, st));
+        if (r2) return r2;
+        HIP_TRY(hipEventRecord(ev[1], st));
+
+        // S2: reverse-neighbour lists
+        const long long total = (long long)n * k;
+        const int gblocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_rn_count, dim3(gblocks), dim3(256), 0, st, g->d_nn, total, d_cnt);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, d_cnt, d_rn_ptr, n);
+        hipLaunchKernelGGL(k_rn_fill, dim3(gblocks), dim3(256), 0, st, g->d_nn, n, k, d_rn_ptr, d_cursor, d_rn_idx);
+        HIP_TRY(hipGetLastError());
+
+        // S3: shared-neighbour rows (count, scan, emit)
+        const size_t lds = (size_t)(((n + 3) / 4 * 4 + 15) / 16) * 16 + (size_t)kRowCap * 8;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_snn_rows<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_snn_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int rblocks = n < cus * 2 ? n : cus * 2;
+        hipLaunchKernelGGL(k_snn_rows<0>, dim3(rblocks), dim3(256), lds, st, g->d_nn, n, k, prune, d_rn_ptr, d_rn_idx, d_deg,
+                           (const int *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, d_err);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, d_deg, d_ptr0, n);
+        HIP_TRY(hipGetLastError());
+        int h_err = 0, nnz0 = 0;
+        HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&nnz0, d_ptr0 + n, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_err) return fail(MI_EUNSUPPORTED, "a point shares neighbours with more than %d others (hub): not supported", kRowCap);
+        if (nnz0 < 0) return fail(MI_EUNSUPPORTED, "SNN graph has more than 2^31 entries");
+        HIP_TRY(hipMalloc((void **)&d_col0, (size_t)(nnz0 > 0 ? nnz0 : 1) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&d_sh0, (size_t)(nnz0 > 0 ? nnz0 : 1) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&d_alive, (size_t)(nnz0 > 0 ? nnz0 : 1)));
+        HIP_TRY(hipMemsetAsync(d_alive, 1, (size_t)(nnz0 > 0 ? nnz0 : 1), st));
+        hipLaunchKernelGGL(k_snn_rows<1>, dim3(rblocks), dim3(256), lds, st, g->d_nn, n, k, prune, d_rn_ptr, d_rn_idx, d_deg,
+                           (const int *)d_ptr0, d_col0, d_sh0, d_err);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[2], st));
+
+        // S4: the sequential symmetric trim, S5: compaction
+        if (ord > 0) hipLaunchKernelGGL(k_trim, dim3(1), dim3(kTrimThreads), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0, d_alive);
+        HIP_TRY(hipMemsetAsync(d_err + 1, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_compact_count, dim3((n + 255) / 256), dim3(256), 0, st, n, (const int *)d_ptr0, d_alive, d_deg, d_err + 1);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, d_deg, g->d_ptr, n);
+        HIP_TRY(hipGetLastError());
+        int nnz1 = 0;
+        HIP_TRY(hipMemcpyAsync(&nnz1, g->d_ptr + n, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&g->max_degree, d_err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        g->nnz = nnz1;
+        HIP_TRY(hipMalloc((void **)&g->d_col, (size_t)(nnz1 > 0 ? nnz1 : 1) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&g->d_shared, (size_t)(nnz1 > 0 ? nnz1 : 1) * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_compact_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, (const int *)d_ptr0, d_col0, d_sh0, d_alive,
+                           (const int *)g->d_ptr, g->d_col, g->d_shared);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[3], st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipEventElapsedTime(&g->ms_knn, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&g->ms_snn, ev[1], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&g->ms_trim, ev[2], ev[3]));
+        return MI_OK;
+    }();
+    void *tmp[] = {dX, d_cnt, d_rn_ptr, d_cursor, d_rn_idx, d_deg, d_ptr0, d_err, d_col0, d_sh0, d_alive};
+    for (void *b : tmp)
+        if (b) (void)hipFree(b);
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+    if (rc) { mi_snn_destroy(g); return rc; }
+    *out = g;
+    return MI_OK;
+}
+
+int mi_snn_info(const mi_snn_graph *g, int *n, int *k, int64_t *nnz, int *max_degree)
+{
+    if (!g) return fail(MI_EINVAL, "NULL graph");
+    if (n) *n = g->n;
+    if (k) *k = g->k;
+    if (nnz) *nnz = g->nnz;
+    if (max_degree) *max_degree = g->max_degree;
+    return MI_OK;
+}
+
+int mi_snn_fetch(mi_snn_graph *g, int32_t *nn, int64_t *rowptr, int32_t *col, int32_t *shared)
+{
+    if (!g) return fail(MI_EINVAL, "NULL graph");
+    HIP_TRY(hipSetDevice(g->device));
+    if (nn) HIP_TRY(hipMemcpy(nn, g->d_nn, (size_t)g->n * g->k * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (rowptr) {
+        std::vector<int> tmp((size_t)g->n + 1);
+        HIP_TRY(hipMemcpy(tmp.data(), g->d_ptr, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) rowptr[i] = tmp[i];
+    }
+    if (col && g->nnz) HIP_TRY(hipMemcpy(col, g->d_col, (size_t)g->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (shared && g->nnz) HIP_TRY(hipMemcpy(shared, g->d_shared, (size_t)g->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_snn_kernel_ms(const mi_snn_graph *g, float *knn_ms, float *snn_ms, float *trim_ms)
+{
+    if (!g) return fail(MI_EINVAL, "NULL graph");
+    if (knn_ms) *knn_ms = g->ms_knn;
+    if (snn_ms) *snn_ms = g->ms_snn;
+    if (trim_ms) *trim_ms = g->ms_trim;
+    return MI_OK;
+}
+
+}  // extern "C"

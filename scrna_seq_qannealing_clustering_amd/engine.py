@@ -93,6 +93,11 @@ class Problem:
         _lib.check(_lib.load().mi_sa_debug_pace(self._h, _ptr(out, C.c_uint32), words))
         return out
 
+    def debug_stats(self, words: int = 16):
+        out = np.zeros(words, dtype=np.uint64)
+        _lib.check(_lib.load().mi_sa_debug_stats(self._h, _ptr(out, C.c_uint64), words))
+        return out
+
     # -- the anneal -----------------------------------------------------------------------------
     @property
     def state_dtype(self):

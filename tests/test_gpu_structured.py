@@ -95,6 +95,61 @@ def test_structured_kernels_beyond_4096_variables():
     assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
 
 
+def _sparse_ring_model(n, seed):
+    """A large sparse symmetric model built directly in CSR (the dense SNN surrogate is O(n^2)): ring
+    neighbours i+-1, i+-2, i+-64, i+-65 (so every variable has neighbours inside AND outside its own
+    64-variable slot) plus random chords, SNN-like weights s/(2k-s), the uniform pair term of A1."""
+    rng = np.random.RandomState(seed)
+    eu = np.concatenate([np.arange(n)] * 4 + [rng.randint(0, n, size=3 * n)])
+    ev = np.concatenate([(np.arange(n) + d) % n for d in (1, 2, 64, 65)] + [rng.randint(0, n, size=3 * n)])
+    keep = eu != ev
+    lo, hi = np.minimum(eu[keep], ev[keep]), np.maximum(eu[keep], ev[keep])
+    key = np.unique(lo.astype(np.int64) * n + hi)
+    lo, hi = (key // n).astype(np.int32), (key % n).astype(np.int32)
+    w = rng.choice(np.array([1 / 9, 2 / 8, 3 / 7, 4 / 6, 1.0]), size=len(lo))
+    rowptr, col, val = models._csr_from_edges(n, lo, hi, -16.0 * w)
+    deg = np.zeros(n)
+    np.add.at(deg, lo, w)
+    np.add.at(deg, hi, w)
+    gamma = 0.05 * w.sum() / n
+    lin = 8.0 * deg + gamma * (1 - n)
+    return rowptr, col, f32(val), f32(lin), float(np.float32(2 * gamma))
+
+
+@pytest.mark.parametrize("n,R,sweeps", [(20000, 3, 3), (45003, 2, 2)])
+def test_csr_rank1_large_models(n, R, sweeps):
+    """K2 beyond the sizes whose fields fit in LDS next to other replicas: n = 20000 (one replica's fields
+    fill most of a CU's LDS) and n = 45003 (fields in a global buffer, neighbour updates by global fp32
+    atomics) -- BASELINE config 4 is n = 50000.  Bit-exact against the oracle, with a re-synchronisation."""
+    args = _sparse_ring_model(n, seed=n)
+    assert int(np.diff(args[0]).max()) <= 64
+    betas = np.geomspace(0.002, 0.5, sweeps)
+    ost, oen, ostats = so.sa_csr_rank1_philox(*args, R, betas, 5, replica_offset=2, resync_interval=2)
+    with Problem.csr_rank1(*args) as p:
+        p.anneal(R, betas, 5, replica_offset=2, resync_interval=2)
+        st, en, info = p.fetch()
+    assert info["accepted"] == int(ostats[1]) and info["accepted"] > n // 4
+    assert np.array_equal(st, ost)
+    assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+
+
+def test_csr_rank1_both_forms_follow_the_same_chain():
+    """The first form of K2 (row hand-off through LDS) and the second (deferred neighbour updates, staged by
+    LDS-DMA) are the same chain; many flips per slot (hot schedule) exercise the staging-area flush."""
+    fx = load_fixture("blobs")
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    args = (m.rowptr, m.col, f32(m.val), f32(m.lin), float(np.float32(m.c_pair)))
+    betas = np.geomspace(1e-4, 1.0, 12)                          # starts at ~100 % acceptance
+    ost, oen, ostats = so.sa_csr_rank1_philox(*args, 70, betas, 3)
+    for variant, waves in ((0, 0), (0, 3), (1, 0)):
+        with Problem.csr_rank1(*args) as p:
+            p.set_option("variant", variant)
+            p.set_option("k2_waves", waves)
+            p.anneal(70, betas, 3)
+            st, en, info = p.fetch()
+        assert np.array_equal(st, ost) and info["accepted"] == int(ostats[1])
+
+
 @pytest.mark.parametrize("name,K", [("noisy_circles", 3), ("blobs", 3), ("aniso", 8), ("no_structure", 15)])
 def test_potts_trajectory_parity(name, K):
     fx = load_fixture(name)
