@@ -202,21 +202,15 @@ int orc_sa_dense_philox(const float *Qs, int n, double offset, int R, uint32_t r
  * symmetric (CSR: rowptr/col/val hold S_ij for every stored neighbour, both directions) and c is
  * the uniform pair coefficient (2*gamma for BQM_clustering.py:46-47).  Local field
  *     f_i = lin_i + sum_j S_ij x_j + c (s - x_i),   s = sum x.
- * The kernel caches g_i = lin_i + sum_j S_ij x_j (fp32, updated per accepted flip on neighbours
- * only) and the integer s; f_i = g_i + c * (float)(s - x_i)  (one fp32 multiply, one add). */
-static void field_init_csr(const int *rowptr, const int *col, const float *val, const float *lin,
-                           int n, const uint8_t *x, float *g, int *s_out)
-{
-    int s = 0;
-    for (int i = 0; i < n; ++i) g[i] = lin[i];
-    for (int j = 0; j < n; ++j) {
-        if (!x[j]) continue;
-        ++s;
-        for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) g[col[e]] = g[col[e]] + val[e];
-    }
-    *s_out = s;
-}
-
+ * Chain: variables are visited in index order, in blocks of 64 consecutive variables ("slots", the
+ * wavefront width of the kernel).  When a slot is entered, the sparse part of the field of each of its
+ * variables is evaluated FRESH from the current state, fp32, in stored CSR order:
+ *     g_i = lin_i ;  for e in row i:  if x[col_e]:  g_i = g_i + val_e
+ * Inside the slot, an accepted flip of i updates the g of its neighbours IN THE SAME SLOT (g_j += sgn*S_ij,
+ * one fp32 add each, in flip order) and the integer s;  f_i = g_i + c * (float)(s - x_i)  (one fp32
+ * multiply, one add).  No field survives a slot, so nothing drifts and there is nothing to re-synchronise
+ * (resync_interval is accepted and ignored). */
+#define ORC_SLOT 64
 int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val, const float *lin,
                             float c_pair, int n, double offset, int R, uint32_t replica_offset,
                             int num_sweeps, const double *betas, uint64_t seed, const uint8_t *init,
@@ -231,31 +225,39 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
     for (int r = 0; r < R; ++r) {
         uint32_t gid = replica_offset + (uint32_t)r;
         uint8_t *x = out_states + (size_t)r * n;
-        float *g = (float *)malloc(sizeof(float) * (size_t)n);
+        float g[ORC_SLOT];
         int S = 0;
         if (init) memcpy(x, init + (size_t)r * n, (size_t)n);
         else
             for (int i = 0; i < n; ++i) x[i] = (uint8_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) >> 31);
-        field_init_csr(rowptr, col, val, lin, n, x, g, &S);
+        for (int i = 0; i < n; ++i) S += x[i];
         for (int s = 0; s < num_sweeps; ++s) {
             float T = temps[betas_per_replica ? r : s];
-            for (int i = 0; i < n; ++i) {
-                float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
-                float fi = g[i] + c_pair * (float)(S - (int)x[i]);
-                float dE = x[i] ? -fi : fi;
-                ++tot_prop;
-                if (dE < thr) {
-                    float sgn = x[i] ? -1.0f : 1.0f;
+            for (int i0 = 0; i0 < n; i0 += ORC_SLOT) {
+                const int i1 = i0 + ORC_SLOT < n ? i0 + ORC_SLOT : n;
+                for (int i = i0; i < i1; ++i) {
+                    float gi = lin[i];
                     for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
-                        g[col[e]] = g[col[e]] + sgn * val[e];
-                    S += x[i] ? -1 : 1;
-                    x[i] ^= 1;
-                    ++tot_acc;
+                        if (x[col[e]]) gi = gi + val[e];
+                    g[i - i0] = gi;
+                }
+                for (int i = i0; i < i1; ++i) {
+                    float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
+                    float fi = g[i - i0] + c_pair * (float)(S - (int)x[i]);
+                    float dE = x[i] ? -fi : fi;
+                    ++tot_prop;
+                    if (dE < thr) {
+                        float sgn = x[i] ? -1.0f : 1.0f;
+                        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+                            if (col[e] >= i0 && col[e] < i1) g[col[e] - i0] = g[col[e] - i0] + sgn * val[e];
+                        S += x[i] ? -1 : 1;
+                        x[i] ^= 1;
+                        ++tot_acc;
+                    }
                 }
             }
-            if (resync_interval > 0 && (s + 1) % resync_interval == 0)
-                field_init_csr(rowptr, col, val, lin, n, x, g, &S);
         }
+        (void)resync_interval;
         double E = 0.0;
         long cnt = 0;
         for (int i = 0; i < n; ++i) {
@@ -269,7 +271,6 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
         }
         E += (double)c_pair * 0.5 * (double)cnt * (double)(cnt - 1);
         out_energy[r] = E + offset;
-        free(g);
     }
     free(temps);
     if (out_stats) { out_stats[0] += tot_prop; out_stats[1] += tot_acc; }

@@ -17,7 +17,7 @@ ap.add_argument("--replicas", type=int, default=4096)
 ap.add_argument("--n", type=int, default=2638)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--check", action="store_true")
-ap.add_argument("arms", nargs="*", default=["variant=1", "variant=0"])
+ap.add_argument("arms", nargs="*", default=["k2_waves=0"])
 a = ap.parse_args()
 nodes, eu, ev, w, _ = graphs.synthetic_snn(a.n, 5, 15, 15, 9, seed=0)
 G = graphs.EdgeListGraph(nodes, eu, ev, w)
@@ -37,7 +37,7 @@ with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(n
             ds = p.debug_stats()
             if ds[8:13].any():
                 tot = float(ds[8:13].sum())
-                print("   phase cycles/wave/sweep: pre %.0f loop %.0f wait %.0f apply %.0f init %.0f" % tuple(
+                print("   phase cycles/wave/sweep: pre %.0f loop %.0f wait %.0f field-sum %.0f slot-top %.0f" % tuple(
                     float(x) / a.replicas / a.sweeps for x in ds[8:13]))
             if a.check:
                 if ref is None:

@@ -99,10 +99,7 @@ struct mi_sa_problem {
     uint32_t *d_ell_col = nullptr;
     float *d_ell_val = nullptr, *d_lin = nullptr;
     uint2 *d_rows = nullptr;                 // K2: row-major adjacency, in-slot neighbours first
-    uint2 *d_rows_out = nullptr;             // K2: the same with in-slot entries blanked
     uint32_t *d_meta = nullptr;              // K2: in-slot count | degree << 8
-    float *d_gbuf = nullptr;                 // K2: fields in global memory (large n), cap_gbuf_R x slots*64
-    size_t cap_gbuf = 0;
     int cus = 0;
     // run buffers
     int cap_R = 0, cap_sweeps = 0;
@@ -126,7 +123,6 @@ struct mi_sa_problem {
     int opt_ondemand_permille = 40;          // K1w: on-demand sweeps below this acceptance (per mille); 0 = always stream
     int opt_debug = 0;                       // DenseArgs::debug (diagnostic timing only; results are wrong)
     int opt_k2_waves = 0;                    // K2: replicas per workgroup (0 = auto)
-    int opt_k2_lds_waves = -1;               // K2: cap on LDS-resident replicas per workgroup (-1 = as many as fit)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
     int last_launches = 1;                   // kernel launches that served the last anneal
@@ -348,10 +344,6 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
         HIP_TRY(hipMalloc((void **)&p->d_rows, hr.size() * sizeof(uint2)));
         HIP_TRY(hipMalloc((void **)&p->d_meta, hm.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(p->d_rows, hr.data(), hr.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        for (int i = 0; i < n; ++i)                         // blank the in-slot entries: (self, +0.0f)
-            for (uint32_t k = 0; k < (hm[i] & 0xffu); ++k) hr[(size_t)i * D + k] = make_uint2((uint32_t)i, 0u);
-        HIP_TRY(hipMalloc((void **)&p->d_rows_out, hr.size() * sizeof(uint2)));
-        HIP_TRY(hipMemcpy(p->d_rows_out, hr.data(), hr.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_meta, hm.data(), hm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     return MI_OK;
@@ -408,7 +400,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_rows, p->d_rows_out, p->d_meta, p->d_gbuf, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_rows, p->d_meta, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -457,8 +449,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "debug")) { p->opt_debug = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_waves") && value >= 0 && value <= 16) { p->opt_k2_waves = (int)value; return MI_OK; }
-    if (!strcmp(key, "k2_lds_waves") && value >= -1 && value <= 16) { p->opt_k2_lds_waves = (int)value; return MI_OK; }
-    if (!strcmp(key, "variant") && value >= 0 && value <= 63) { p->opt_variant = (int)value; return MI_OK; }
+    if (!strcmp(key, "variant") && value >= 0 && value <= 4) { p->opt_variant = (int)value; return MI_OK; }
     if (!strcmp(key, "unit_rows") && (value == 0 || value == 2 || value == 4)) { p->opt_unit_rows = (int)value; return MI_OK; }
     return fail(MI_EINVAL, "unknown option '%s'", key);
 }
@@ -513,19 +504,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         a.resync = resync_interval; a.slots = p->slots; a.D = p->D;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
-        a.rows = p->d_rows; a.rows_out = p->d_rows_out; a.meta = p->d_meta; a.gbuf = nullptr; a.variant = p->opt_variant; a.cus = p->cus; a.waves_override = p->opt_k2_waves;
-        a.lds_waves_override = p->opt_k2_lds_waves; a.lds_waves = 0; a.g_bytes = 0;
-        if (p->kind == MI_KIND_CSR_RANK1 && (p->opt_variant & 15) != 1) {
-            K2Plan pl;
-            mi_k2_plan(p->n, p->slots, R, p->cus > 0 ? p->cus : 256, p->opt_k2_waves, p->opt_k2_lds_waves, &pl);
-            if (pl.gbuf_floats > p->cap_gbuf) {     // fields that do not fit in LDS live in HBM / Infinity Cache
-                if (p->d_gbuf) (void)hipFree(p->d_gbuf);
-                p->d_gbuf = nullptr; p->cap_gbuf = 0;
-                HIP_TRY(hipMalloc((void **)&p->d_gbuf, pl.gbuf_floats * sizeof(float)));
-                p->cap_gbuf = pl.gbuf_floats;
-            }
-            a.gbuf = p->d_gbuf;
-        }
+        a.rows = p->d_rows; a.meta = p->d_meta; a.waves_override = p->opt_k2_waves;
         if (p->kind == MI_KIND_POTTS_CSR && init) {
             // labels must be < K: validated on the host copy (the device trusts them as cnt[] indices)
             const uint16_t *l = static_cast<const uint16_t *>(init);

@@ -222,21 +222,12 @@ struct EllArgs {
     uint32_t replica_offset, seed_lo, seed_hi;
     uint32_t sweep_offset;     // see DenseArgs
     int temps_per_replica;
-    // K2 second form (k_anneal_csr_rank1_v2)
-    const uint2 *rows;         // [slots*64][D] (col, val bits) row-major, in-slot neighbours first, padding (self, +0)
-    const uint2 *rows_out;     // same rows with the in-slot entries blanked to (self, +0): the deferred updates
+    // K2: row-major copy of the adjacency with the neighbours inside the variable's own 64-slot first
+    const uint2 *rows;         // [slots*64][D] (col, val bits), padding (self, +0)
     const uint32_t *meta;      // per variable: in-slot neighbour count | degree << 8
-    float *gbuf;               // fields in global memory, R x slots*64 (only when they do not fit in LDS)
-    int variant;               // K2: 0 auto (second form), 1 first form
-    int cus;                   // compute units of the device (launch shaping)
-    int waves_override;        // replicas per workgroup (0 = automatic)
-    int lds_waves_override;    // cap on the replicas per workgroup whose fields live in LDS (-1 = as many as fit)
-    int lds_waves, g_bytes;    // set by the launcher: see mi_k2_plan
+    int waves_override;        // K2: replicas per workgroup (0 = default)
 };
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
-// launch shape of the second form of K2 (one definition for the launcher and for the host code that sizes gbuf)
-struct K2Plan { int waves, lds_waves, g_bytes, blocks; size_t lds_bytes, gbuf_floats; };
-void mi_k2_plan(int n, int slots, int R, int cus, int waves_override, int lds_waves_override, K2Plan *out);
 int mi_launch_potts(const EllArgs &, hipStream_t);
 
 // K4 launcher (energy_kernels.hip); all pointers are device pointers

@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/mi_sa.h declares (no compute: CPU box)."""
+"""The C-ABI library loads and exports every symbol include/*.h declares (no compute: CPU box)."""
 import ctypes
 import os
 import re
@@ -11,9 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_functions():
-    src = open(os.path.join(ROOT, "include", "mi_sa.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+    names = set()
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_is_built():
