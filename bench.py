@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""bench.py -- spin-flip updates/s of the dense-QUBO anneal on the PBMC3k-sized SNN model.
+"""bench.py -- spin-flip updates/s of the anneal on the PBMC3k-sized SNN graph-partition model.
 
 Workload (BASELINE.json configs[1]): synthetic PBMC3k-like SNN graph, n = 2638 cells (k=5, dim=15,
 trim 15; no PBMC data ships with the reference), `clustering_bqm` model (BQM_clustering.py:29-47,
-gamma_factor 0.05, k 8) as a dense fp32 Q (27.8 MB) resident in HBM; ONE STEP = one anneal of
-4096 replicas x 1000 sweeps per GPU (explicit geometric beta schedule, seed 1234).
+gamma_factor 0.05, k 8) resident in HBM; ONE STEP = one anneal of 4096 replicas x 1000 sweeps per GPU
+(explicit geometric beta schedule, seed 1234).  The timed kernel is the one `MI355XSampler.sample_qubo`
+runs for this model: K2, the CSR form (sparse cut term + uniform pair term; dE = Q_i . x evaluated from
+the CSR rows).  The dense form (K1w, 27.8 MB fp32 Q) and the Potts kernel run beside it, untimed
+(`other_kernels`); `--kernel dense` makes the dense kernel the timed one.
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
@@ -12,10 +15,11 @@ Multi-GPU: replicas shard (weak scaling: 4096 replicas per GPU, global ids rank*
 replicated, and each step ends with the ONE exchange the path has: a 64-bit MIN all-reduce of the
 packed (energy, replica id) key + a broadcast of the winner's labels (RCCL over xGMI).
 
-Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes (4n per proposal, SURVEY.md
-section 8d) / HIP-event kernel time; it exceeds HBM peak when rows are served from L2 / Infinity Cache
-and because cached local fields need a row only for ACCEPTED moves -- `rows_GBps` gives the bytes the
-kernel really requested.  `cpu_baseline` times the oracle's neal restatement on this host.
+Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes per update (SURVEY.md section 8d:
+CSR deg_i*8 + 8 averaged over the variables; dense 4n) x updates per launch / mean launch time (HIP
+events).  The model (0.34 MB in CSR form, 27.8 MB dense) lives in L2 / Infinity Cache, so this is an
+effective-bandwidth figure; `traffic` is what the fabric counters saw.  `cpu_baseline` times the oracle's
+neal restatement on this host.
 """
 import argparse
 import json
@@ -72,7 +76,7 @@ def cpu_baseline(Qs, betas, seconds_target=15.0):
     }
 
 
-def pmc_traffic(replicas, sweeps, launches):
+def pmc_traffic(replicas, sweeps, launches, kernel):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload
     (profiles/r01_pmc_traffic.json, written by scripts/pmc_traffic.py on the GPU box: FETCH_SIZE doubled
     per the gfx950 note + WRITE_SIZE, averaged over the launches of one step).  None when no profile matches
@@ -82,30 +86,37 @@ def pmc_traffic(replicas, sweeps, launches):
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("launches") == launches:
+    if (rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("launches") == launches
+            and rec.get("kernel") == kernel):
         return float(rec["hbm_bytes_per_launch"])
     return None
 
 
-def other_kernels(m, betas, graph, rank_device):
-    """Short untimed-region runs of the structured kernels on the same graph (reported beside the headline,
-    never part of `value`): K2 = the same QUBO in CSR + uniform-pair form, K3 = BASELINE config 3 (DQM K=8)."""
+def other_kernels(m, Qs, betas, graph, rank_device, headline):
+    """Short untimed-region runs of the other kernels on the same graph (reported beside the headline, never
+    part of `value`): the same QUBO on the other binary kernel, and K3 = BASELINE config 3 (DQM K=8)."""
     from scrna_seq_qannealing_clustering_amd import models
     from scrna_seq_qannealing_clustering_amd.engine import Problem
     from scrna_seq_qannealing_clustering_amd.sampler import default_potts_beta_range
     out = {}
     n = m.num_variables
     R, S = REPLICAS_PER_GPU, 200
-    with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                           float(np.float32(m.c_pair)), device=rank_device) as p:
-        b = models.make_beta_schedule(S, models.default_beta_range(m))
+    b = models.make_beta_schedule(S, models.default_beta_range(m))
+    if headline == "csr":
+        p = Problem.dense(Qs, offset=0.0, device=rank_device)
+        name, kname = "dense_bqm", "k_anneal_dense_wg<44,4>"
+    else:
+        p = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
+                              float(np.float32(m.c_pair)), device=rank_device)
+        name, kname = "csr_rank1_bqm", "k_anneal_csr_rank1<16>"
+    with p:
         p.anneal(R, b, SEED)
         ms = p.kernel_ms()
         st, en, info = p.fetch()
-        out["csr_rank1_bqm"] = {"kernel": "k_anneal_csr_rank1<16>", "replicas": R, "sweeps": S, "kernel_ms": ms,
-                                "updates_per_s": R * S * n / (ms * 1e-3),
-                                "best_energy": float(m.energies(st[int(np.argmin(en))][None, :])[0]),
-                                "acceptance": info["accepted"] / info["proposals"]}
+        out[name] = {"kernel": kname, "replicas": R, "sweeps": S, "kernel_ms": ms,
+                     "updates_per_s": R * S * n / (ms * 1e-3),
+                     "best_energy": float(m.energies(st[int(np.argmin(en))][None, :])[0]),
+                     "acceptance": info["accepted"] / info["proposals"]}
     pm = models.build_dqm_potts(graph, 8, 0.005)
     with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(np.float32), float(np.float32(pm.c_pair)), n, 8,
                            lin_offset=pm.lin_offset, device=rank_device) as p:
@@ -126,6 +137,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
     ap.add_argument("--sweeps", type=int, default=SWEEPS)
+    ap.add_argument("--kernel", choices=("csr", "dense"), default="csr",
+                    help="timed kernel: csr = K2 (what the sampler runs for this model), dense = K1w")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -152,7 +165,16 @@ def main():
         betas = models.make_beta_schedule(args.sweeps, models.default_beta_range(m))
     R = args.replicas
     n = Qs.shape[0]
-    prob = Problem.dense(Qs, offset=0.0, device=local)             # Q resident in HBM before timing
+    if args.kernel == "dense":                                     # model resident in HBM before timing
+        prob = Problem.dense(Qs, offset=0.0, device=local)
+        kernel_name, bytes_per_update = "k_anneal_dense_wg<44,4>", 4.0 * n
+        layout = "dense fp32 Q 27.8 MB"
+    else:
+        prob = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
+                                 float(np.float32(m.c_pair)), device=local)
+        kernel_name = "k_anneal_csr_rank1<16>"
+        bytes_per_update = 8.0 * float(np.diff(m.rowptr).mean()) + 8.0      # deg_i*(4+4) + 8
+        layout = "CSR (cut term) + uniform pair term, %.1f neighbours per cell on average" % float(np.diff(m.rowptr).mean())
 
     def step(i):
         prob.anneal(R, betas, SEED + i, replica_offset=rank * R)
@@ -188,9 +210,12 @@ def main():
     k_ms = float(np.mean(kernel_ms))                               # all launches of one step
     launch_ms = k_ms / launches                                    # = rocprofv3's average duration of the kernel
     sweeps_per_launch = len(betas) / launches
-    alg_bytes = 4.0 * n * R * sweeps_per_launch * n                # per launch (one GPU)
+    alg_bytes = bytes_per_update * R * sweeps_per_launch * n       # per launch (one GPU)
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-    row_bytes = info["accepted"] * (((n + 255) // 256) * 256 * 4)  # padded row actually requested
+    if args.kernel == "dense":
+        row_bytes = info["accepted"] * (((n + 255) // 256) * 256 * 4)   # padded rows the accepted flips consumed
+    else:
+        row_bytes = R * len(betas) * ((n + 63) // 64) * 64 * (16 * 8 + 4 + 4 + 32)   # per slot: adjacency, lin, meta, 4 in-slot entries
     best_state = best[3]
     cut_edges = int(np.sum(best_state[eu] != best_state[ev]))
     out = {
@@ -199,15 +224,16 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PBMC3k-sized synthetic SNN (n=2638, k=5, dim=15, trim 15), clustering_bqm QUBO "
-                               "(gamma_factor 0.05, k 8), dense fp32 Q 27.8 MB in HBM, %d replicas/GPU x %d sweeps, "
-                               "geometric beta, seed 1234" % (R, len(betas)),
+                               "(gamma_factor 0.05, k 8), %s, resident in HBM, %d replicas/GPU x %d sweeps, "
+                               "geometric beta, seed 1234" % (layout, R, len(betas)),
+                   "kernel": args.kernel,
                    "n": n, "replicas_per_gpu": R, "sweeps": int(len(betas)), "parallelism": "replicas sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(R, len(betas), launches),
-                     "kernel": "k_anneal_dense_wg<44,4>", "kernel_ms": launch_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(R, len(betas), launches, kernel_name),
+                     "kernel": kernel_name, "kernel_ms": launch_ms,
                      "launches_per_step": launches, "sweeps_per_launch": sweeps_per_launch,
                      "kernel_ms_per_step": k_ms,
-                     "algorithmic_bytes_per_update": 4 * n,
+                     "algorithmic_bytes_per_update": bytes_per_update,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "rows_GBps": row_bytes / (k_ms * 1e-3) / 1e9,
                      "acceptance": info["accepted"] / info["proposals"]},
@@ -218,7 +244,7 @@ def main():
     }
     if rank == 0:
         if world == 1:
-            out["other_kernels"] = other_kernels(m, betas, graph, local)
+            out["other_kernels"] = other_kernels(m, Qs, betas, graph, local, args.kernel)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(Qs, betas)
         else:

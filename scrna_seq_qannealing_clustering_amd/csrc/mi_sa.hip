@@ -321,8 +321,8 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
     HIP_TRY(hipMemcpy(p->d_ell_val, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
     p->slots = slots;
     p->D = D;
-    if (p->kind == MI_KIND_CSR_RANK1) {
-        // row-major copy for the second form of K2: neighbours in the variable's own 64-slot first
+    {
+        // row-major copy (K2, K3): neighbours in the variable's own 64-slot first
         std::vector<uint2> hr((size_t)slots * 64 * D);
         std::vector<uint32_t> hm((size_t)slots * 64, 0u);
         for (int i = 0; i < slots * 64; ++i) {

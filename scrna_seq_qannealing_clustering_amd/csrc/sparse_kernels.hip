@@ -229,10 +229,14 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(Ell
 // LDS per wave: labels, one byte per variable (K <= 64).  Lane q of the wave keeps cnt[q] (cluster sizes).
 // Proposal of variable i: a = l_i, b = (a + 1 + word(i,s,g,2) mod (K-1)) mod K;
 //   dE = [h_b + c cnt_b] - [h_a + c (cnt_a - 1)],  h_q = sum of S_ij over neighbours j with l_j = q
-// (h sums taken in stored neighbour order, fp32 -- oracle 2c).  After a commit every later lane of the
-// slot re-evaluates from its register-resident adjacency row.
+// (h sums taken in stored neighbour order, fp32 -- oracle 2c).  Same loop economy as K2: the slot's
+// adjacency is prefetched one slot ahead; inside the slot a commit moves two cluster sizes (every lane
+// patches the sizes of ITS two labels with +-1.0, exact) and re-evaluates h only on the lanes that have the
+// moved variable among their neighbours -- found from the mover's in-slot neighbour list (`rows` / `meta`,
+// as in K2), not by scanning every lane's row.  A mover is never tested again in its slot, so its label is
+// written after the loop -- unless it has in-slot neighbours, which read it back at once.
 template <int D>
-__global__ void __launch_bounds__(256) k_anneal_potts(EllArgs a)
+__global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -243,6 +247,7 @@ __global__ void __launch_bounds__(256) k_anneal_potts(EllArgs a)
     const int n = a.n, slots = a.slots, K = a.K;
     uint8_t *lab = reinterpret_cast<uint8_t *>(lds) + (size_t)wave * slots * 64;
     const uint16_t *init = static_cast<const uint16_t *>(a.init);
+    const uint2 *rows = a.rows;
 
     for (int tg = 0; tg * 4 < slots; ++tg) {
         uint32_t w[4] = {0, 0, 0, 0};
@@ -265,68 +270,92 @@ __global__ void __launch_bounds__(256) k_anneal_potts(EllArgs a)
         if (lane == q) cntv = c;
     }
 
+    constexpr bool PF = (D == 16);
+    struct SlotAdj { uint32_t col[D]; float val[D]; };
+    auto fetch_adj = [&](int t) {
+        SlotAdj p;
+        const int tt = t < slots ? t : slots - 1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            p.col[k] = a.ell_col[((size_t)tt * D + k) * 64 + lane];
+            p.val[k] = a.ell_val[((size_t)tt * D + k) * 64 + lane];
+        }
+        return p;
+    };
+
     unsigned long long accepted = 0;
     for (int s = 0; s < a.num_sweeps && K > 1; ++s) {
         const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
             __float_as_int(a.temps[a.temps_per_replica ? r : s])));
-        for (int tg = 0; tg * 4 < slots; ++tg) {
-            uint32_t w0[4], w2[4];
-            slot_words(w0, tg, lane, (uint32_t)s + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
-            slot_words(w2, tg, lane, (uint32_t)s + a.sweep_offset, gid, 2u, a.seed_lo, a.seed_hi);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int t = 4 * tg + c;
-                if (t >= slots) break;
-                const int i = t * 64 + lane;
-                uint32_t colv[D];
-                float valv[D];
+        SlotAdj nxt;
+        if constexpr (PF) nxt = fetch_adj(0);
+        uint32_t w0[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+        for (int t = 0; t < slots; ++t) {                    // ONE copy of the slot body
+            if ((t & 3) == 0) {
+                slot_words(w0, t >> 2, lane, (uint32_t)s + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
+                slot_words(w2, t >> 2, lane, (uint32_t)s + a.sweep_offset, gid, 2u, a.seed_lo, a.seed_hi);
+            }
+            const int c = t & 3;
+            const uint32_t w0c = c == 0 ? w0[0] : (c == 1 ? w0[1] : (c == 2 ? w0[2] : w0[3]));
+            const uint32_t w2c = c == 0 ? w2[0] : (c == 1 ? w2[1] : (c == 2 ? w2[2] : w2[3]));
+            const int i = t * 64 + lane;
+            // the mover's in-slot neighbours (lane ids): issued before the prefetch (loads return in order)
+            const uint32_t metav = a.meta[i];
+            const uint4 e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D);
+            const uint4 e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D + 2);
+            asm volatile("" ::: "memory");
+            SlotAdj cur;
+            if constexpr (PF) { cur = nxt; nxt = fetch_adj(t + 1); } else { cur = fetch_adj(t); }
+            float thr = neglog_u(w0c) * T;
+            if (i >= n) thr = -INFINITY;
+            const int la = lab[i];
+            const int lb = (la + 1 + (int)(w2c % (uint32_t)(K - 1))) % K;
+            float ha = 0.0f, hb = 0.0f;
+            auto sum_h = [&]() {
+                ha = 0.0f;
+                hb = 0.0f;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    colv[k] = a.ell_col[((size_t)t * D + k) * 64 + lane];
-                    valv[k] = a.ell_val[((size_t)t * D + k) * 64 + lane];
+                    const int lj = lab[cur.col[k]];
+                    ha = ha + ((lj == la) ? cur.val[k] : 0.0f);
+                    hb = hb + ((lj == lb) ? cur.val[k] : 0.0f);
                 }
-                float thr = neglog_u(w0[c]) * T;
-                if (i >= n) thr = -INFINITY;
-                int la = lab[i];
-                const int lb = (la + 1 + (int)(w2[c] % (uint32_t)(K - 1))) % K;
-                uint64_t todo = ~0ull;
-                // h_a / h_b are summed from scratch (stored neighbour order) at the slot start and again
-                // only for lanes that have the committed variable among their neighbours -- for every
-                // other lane the cached sums ARE what a fresh evaluation would give; cluster sizes change
-                // for everybody and enter through cnt.
-                float ha = 0.0f, hb = 0.0f;
-                auto sum_h = [&]() {
-                    ha = 0.0f;
-                    hb = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const int lj = lab[colv[k]];
-                        ha = ha + ((lj == la) ? valv[k] : 0.0f);
-                        hb = hb + ((lj == lb) ? valv[k] : 0.0f);
-                    }
-                };
-                sum_h();
-                while (true) {
-                    const int ca = __shfl(cntv, la, 64), cb = __shfl(cntv, lb, 64);
-                    const float ea = ha + a.c_pair * (float)(ca - 1);
-                    const float eb = hb + a.c_pair * (float)cb;
-                    const float dE = eb - ea;
-                    const uint64_t m = __ballot(dE < thr) & todo;
-                    if (m == 0) break;
-                    const int l = __ffsll((unsigned long long)m) - 1;
-                    todo = (~0ull << l) << 1;
-                    const int a_s = __builtin_amdgcn_readlane(la, l);
-                    const int b_s = __builtin_amdgcn_readlane(lb, l);
-                    if (lane == l) { lab[i] = (uint8_t)lb; la = lb; }
-                    if (lane == a_s) cntv -= 1;
-                    if (lane == b_s) cntv += 1;
-                    const uint32_t moved = (uint32_t)(t * 64 + l);
-                    bool touched = false;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) touched |= (colv[k] == moved);
-                    if (touched && lane > l) sum_h();          // padding (self) never equals `moved` for lane > l
-                    ++accepted;
+            };
+            sum_h();
+            float fa = (float)(__shfl(cntv, la, 64) - 1), fb = (float)__shfl(cntv, lb, 64);
+            const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
+            uint64_t todo = ~0ull, flipped = 0ull;
+            asm volatile("" ::"v"(metav), "v"(e01.x), "v"(e01.z), "v"(e23.x), "v"(e23.z));
+            while (true) {
+                const float ea = ha + a.c_pair * fa;
+                const float eb = hb + a.c_pair * fb;
+                const float dE = eb - ea;
+                const uint64_t m = __ballot(dE < thr) & todo;
+                if (m == 0) break;
+                const int l = __ffsll((unsigned long long)m) - 1;
+                todo = (~0ull << l) << 1;
+                flipped |= 1ull << l;
+                const int a_s = __builtin_amdgcn_readlane(la, l);
+                const int b_s = __builtin_amdgcn_readlane(lb, l);
+                if (lane == a_s) cntv -= 1;
+                if (lane == b_s) cntv += 1;
+                fa += (la == b_s ? 1.0f : 0.0f) - (la == a_s ? 1.0f : 0.0f);
+                fb += (lb == b_s ? 1.0f : 0.0f) - (lb == a_s ? 1.0f : 0.0f);
+                if ((has_in >> l) & 1ull) {                  // wave-uniform: l has neighbours inside this slot
+                    if (lane == l) lab[i] = (uint8_t)lb;
+                    const int nin = (int)(__builtin_amdgcn_readlane((int)metav, l) & 0xff);
+                    bool touched = lane == (int)(__builtin_amdgcn_readlane((int)e01.x, l) & 63);
+                    if (nin > 1) touched |= lane == (int)(__builtin_amdgcn_readlane((int)e01.z, l) & 63);
+                    if (nin > 2) touched |= lane == (int)(__builtin_amdgcn_readlane((int)e23.x, l) & 63);
+                    if (nin > 3) touched |= lane == (int)(__builtin_amdgcn_readlane((int)e23.z, l) & 63);
+                    for (int k = 4; k < nin; ++k) touched |= lane == (int)(rows[((size_t)t * 64 + l) * D + k].x & 63u);
+                    if (touched) sum_h();
                 }
+            }
+            if (flipped) {                                   // wave-uniform
+                accepted += (unsigned long long)__popcll(flipped);
+                if ((flipped >> lane) & 1ull) lab[i] = (uint8_t)lb;
             }
         }
     }

@@ -220,7 +220,11 @@ class MI355XSampler:
         kernel = kw.get("kernel", "auto")
         if kernel not in ("auto", "dense", "csr"):
             raise ValueError("kernel must be 'auto', 'dense' or 'csr'")
-        use_csr = (kernel == "csr") or (kernel == "auto" and model._dense is None and n > 4096)
+        # structured models (sparse couplings + one uniform pair term: every graph-partition QUBO of the
+        # reference) run on the CSR kernel at any size -- it is the faster one and needs no n x n matrix;
+        # general QUBOs, and rows wider than the 64-entry adjacency layout, run on the dense kernel
+        max_deg = int(np.diff(model.rowptr).max()) if n else 0
+        use_csr = (kernel == "csr") or (kernel == "auto" and model._dense is None and (max_deg <= 64 or n > 4096))
         if use_csr and model._dense is not None:
             raise ValueError("kernel='csr' needs a structured (CSR + uniform pair) model")
         if use_csr:
