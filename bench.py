@@ -171,7 +171,7 @@ def main():
         layout = "dense fp32 Q 27.8 MB"
     else:
         prob = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                                 float(np.float32(m.c_pair)), device=local)
+                                 float(np.float32(m.c_pair)), device=local, order="slots")   # as the sampler does
         kernel_name = "k_anneal_csr_rank1<16>"
         bytes_per_update = 8.0 * float(np.diff(m.rowptr).mean()) + 8.0      # deg_i*(4+4) + 8
         layout = "CSR (cut term) + uniform pair term, %.1f neighbours per cell on average" % float(np.diff(m.rowptr).mean())

@@ -17,6 +17,7 @@ ap.add_argument("--replicas", type=int, default=4096)
 ap.add_argument("--n", type=int, default=2638)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--order", default=None)
 ap.add_argument("arms", nargs="*", default=["k2_waves=0"])
 a = ap.parse_args()
 nodes, eu, ev, w, _ = graphs.synthetic_snn(a.n, 5, 15, 15, 9, seed=0)
@@ -25,7 +26,7 @@ m = models.build_bqm_qubo(G, 0.05, k=8)
 betas = models.make_beta_schedule(a.sweeps, models.default_beta_range(m))
 ref = None
 with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                       float(np.float32(m.c_pair))) as p:
+                       float(np.float32(m.c_pair)), order=a.order) as p:
     for rnd in range(a.rounds):
         for arm in a.arms:
             for kv in arm.split(","):

@@ -145,41 +145,77 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(Ell
             K2_TICK(t_apply);
             float thr = neglog_u(wc) * T;
             if (i >= n) thr = -INFINITY;
-            const uint64_t xm_t = xm[t];
+            const uint64_t xm_v = xm[t];                     // same word in every lane: make it scalar
+            const uint64_t xm_t = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xm_v >> 32)) << 32) |
+                                  (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xm_v);
             const uint32_t xi = (uint32_t)((xm_t >> lane) & 1ull);
             const uint32_t sgnbit = xi << 31;                // dE = x ? -f : f
-            float Sf = (float)(S - (int)xi);
             const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
             uint64_t todo = ~0ull, flipped = 0ull;
-            // wait for this slot's small loads HERE (a counted wait that leaves the prefetch in flight): left
-            // to hipcc the wait lands at their first use inside the loop
-            asm volatile("" ::"v"(metav), "v"(e01.x), "v"(e01.y), "v"(e01.z), "v"(e01.w), "v"(e23.x), "v"(e23.y),
-                         "v"(e23.z), "v"(e23.w));
-            K2_TICK(t_pre);
-            while (true) {
-                const float fi = gi + a.c_pair * Sf;
-                const float dE = __uint_as_float(__float_as_uint(fi) ^ sgnbit);
-                const uint64_t m = __ballot(dE < thr) & todo;
-                if (m == 0) break;
-                const int l = __ffsll((unsigned long long)m) - 1;
-                todo = (~0ull << l) << 1;
-                flipped |= 1ull << l;
-                const bool xl = (xm_t >> l) & 1ull;          // the lane's bit BEFORE its (only) flip in this slot
-                const float sgn = xl ? -1.0f : 1.0f;
-                S += xl ? -1 : 1;
-                Sf += sgn;
-                if ((has_in >> l) & 1ull) {                  // wave-uniform: l has neighbours inside this slot
-                    const int nin = (int)(__builtin_amdgcn_readlane((int)metav, l) & 0xff);
-                    auto hit = [&](uint32_t cc, uint32_t vv) {
-                        if (lane == (int)(cc & 63u)) gi = gi + sgn * __uint_as_float(vv);
-                    };
-                    hit(__builtin_amdgcn_readlane((int)e01.x, l), __builtin_amdgcn_readlane((int)e01.y, l));
-                    if (nin > 1) hit(__builtin_amdgcn_readlane((int)e01.z, l), __builtin_amdgcn_readlane((int)e01.w, l));
-                    if (nin > 2) hit(__builtin_amdgcn_readlane((int)e23.x, l), __builtin_amdgcn_readlane((int)e23.y, l));
-                    if (nin > 3) hit(__builtin_amdgcn_readlane((int)e23.z, l), __builtin_amdgcn_readlane((int)e23.w, l));
-                    for (int k = 4; k < nin; ++k) {
-                        const uint2 e = rows[((size_t)t * 64 + l) * D + k];
-                        hit(e.x, e.y);
+            if (has_in == 0ull) {
+                // ---- no variable of this slot has a neighbour inside it: decisions depend on s alone --------
+                // dE_i(u) = +-(g_i + c*u), u = (float)(s - x_i), is monotone in u (fp32 rounding is monotone), so
+                // "lane i accepts" is a half-line in s.  Its end point is found by bisecting the EXACT fp32
+                // predicate over the 127 values s can take inside this slot (|s - s0| <= 63), and the serial
+                // loop becomes integer: two VALU instructions per accepted flip instead of nine.
+                const bool down = (a.c_pair >= 0.0f) == (xi == 0u);       // accepts for SMALL s (else for large s)
+                const float sig = down ? 1.0f : -1.0f;
+                const float u0 = (float)(S - (int)xi);
+                float J = -64.0f;                                         // accepts iff sig*(s - s0) <= J
+#pragma unroll
+                for (int step = 64; step >= 1; step >>= 1) {
+                    const float cand = J + (float)step;
+                    const float u = __fmaf_rn(sig, cand, u0);             // small integers: exact
+                    const float fi = gi + a.c_pair * u;
+                    const float dE = __uint_as_float(__float_as_uint(fi) ^ sgnbit);
+                    J = (dE < thr) ? cand : J;
+                }
+                const int Ji = (int)J;
+                const int lo = down ? -64 : -Ji;                          // accepts iff lo <= s - s0 <= lo + width
+                const unsigned int width = (unsigned int)(Ji + 64);
+                K2_TICK(t_pre);
+                int dS = 0;
+                while (true) {
+                    const uint64_t m = __ballot((unsigned int)(dS - lo) <= width) & todo;
+                    if (m == 0) break;
+                    const int l = __ffsll((unsigned long long)m) - 1;
+                    todo = (~0ull << l) << 1;
+                    flipped |= 1ull << l;
+                    dS += ((xm_t >> l) & 1ull) ? -1 : 1;
+                }
+                S += dS;
+            } else {
+                float Sf = (float)(S - (int)xi);
+                // wait for this slot's small loads HERE (a counted wait that leaves the prefetch in flight): left
+                // to hipcc the wait lands at their first use inside the loop
+                asm volatile("" ::"v"(metav), "v"(e01.x), "v"(e01.y), "v"(e01.z), "v"(e01.w), "v"(e23.x), "v"(e23.y),
+                             "v"(e23.z), "v"(e23.w));
+                K2_TICK(t_pre);
+                while (true) {
+                    const float fi = gi + a.c_pair * Sf;
+                    const float dE = __uint_as_float(__float_as_uint(fi) ^ sgnbit);
+                    const uint64_t m = __ballot(dE < thr) & todo;
+                    if (m == 0) break;
+                    const int l = __ffsll((unsigned long long)m) - 1;
+                    todo = (~0ull << l) << 1;
+                    flipped |= 1ull << l;
+                    const bool xl = (xm_t >> l) & 1ull;          // the lane's bit BEFORE its (only) flip in this slot
+                    const float sgn = xl ? -1.0f : 1.0f;
+                    S += xl ? -1 : 1;
+                    Sf += sgn;
+                    if ((has_in >> l) & 1ull) {                  // wave-uniform: l has neighbours inside this slot
+                        const int nin = (int)(__builtin_amdgcn_readlane((int)metav, l) & 0xff);
+                        auto hit = [&](uint32_t cc, uint32_t vv) {
+                            if (lane == (int)(cc & 63u)) gi = gi + sgn * __uint_as_float(vv);
+                        };
+                        hit(__builtin_amdgcn_readlane((int)e01.x, l), __builtin_amdgcn_readlane((int)e01.y, l));
+                        if (nin > 1) hit(__builtin_amdgcn_readlane((int)e01.z, l), __builtin_amdgcn_readlane((int)e01.w, l));
+                        if (nin > 2) hit(__builtin_amdgcn_readlane((int)e23.x, l), __builtin_amdgcn_readlane((int)e23.y, l));
+                        if (nin > 3) hit(__builtin_amdgcn_readlane((int)e23.z, l), __builtin_amdgcn_readlane((int)e23.w, l));
+                        for (int k = 4; k < nin; ++k) {
+                            const uint2 e = rows[((size_t)t * 64 + l) * D + k];
+                            hit(e.x, e.y);
+                        }
                     }
                 }
             }

@@ -16,13 +16,14 @@ def _ptr(a, ctype):
 class Problem:
     """A model uploaded to one MI355X.  ``anneal`` is asynchronous; ``fetch``/``best`` wait."""
 
-    def __init__(self, handle, kind, n, num_cases, device):
+    def __init__(self, handle, kind, n, num_cases, device, perm=None):
         self._h = handle
         self.kind = kind
         self.n = n
         self.num_cases = num_cases
         self.device = device
         self._last = None
+        self.perm = perm                 # device variable j is the caller's variable perm[j] (None: identity)
 
     # -- constructors ---------------------------------------------------------------------------
     @classmethod
@@ -41,7 +42,19 @@ class Problem:
 
     @classmethod
     def csr_rank1(cls, rowptr, col, val, lin, c_pair: float, offset: float = 0.0,
-                  device: int = 0) -> "Problem":
+                  device: int = 0, order: Optional[str] = None) -> "Problem":
+        """``order="slots"`` renumbers the variables on the device so that the 64 variables a wavefront
+        sweeps together are (as far as possible) mutually non-adjacent -- the kernel's integer fast path
+        (models.slot_independent_order).  States go in and come out in the CALLER's order either way; the
+        chain is a different (equally valid) sweep order, so results differ from ``order=None`` runs."""
+        perm = None
+        if order == "slots":
+            from .models import permute_csr, slot_independent_order
+            perm = slot_independent_order(rowptr, col)
+            rowptr, col, val = permute_csr(rowptr, col, val, perm)
+            lin = np.asarray(lin)[perm]
+        elif order is not None:
+            raise ValueError("order must be None or 'slots'")
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         col = np.ascontiguousarray(col, dtype=np.int32)
         val = np.ascontiguousarray(val, dtype=np.float32)
@@ -52,7 +65,7 @@ class Problem:
         _lib.check(lib.mi_sa_problem_create_csr_rank1_f32(
             _ptr(rowptr, C.c_int32), _ptr(col, C.c_int32), _ptr(val, C.c_float),
             _ptr(lin, C.c_float), float(c_pair), n, float(offset), int(device), C.byref(h)))
-        return cls(h, _lib.KIND_CSR_RANK1, n, 2, device)
+        return cls(h, _lib.KIND_CSR_RANK1, n, 2, device, perm=perm)
 
     @classmethod
     def potts_csr(cls, rowptr, col, val, c_pair: float, n: int, num_cases: int,
@@ -121,6 +134,8 @@ class Problem:
             if init.shape != (num_reads, self.n):
                 raise ValueError("initial_states must have shape (num_reads, n) = (%d, %d)"
                                  % (num_reads, self.n))
+            if self.perm is not None:
+                init = np.ascontiguousarray(init[:, self.perm])
         _lib.check(_lib.load().mi_sa_anneal_ex(
             self._h, int(num_reads), C.c_uint32(int(replica_offset) & 0xFFFFFFFF), sweeps,
             _ptr(betas, C.c_double), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
@@ -154,6 +169,10 @@ class Problem:
             _ptr(en, C.c_double), _ptr(stats, C.c_uint64)))
         info = {"proposals": int(R) * int(self._last[1]) * int(self.n),
                 "accepted": int(stats[1]), "row_bytes": int(stats[2])}
+        if st is not None and self.perm is not None:
+            out = np.empty_like(st)
+            out[:, self.perm] = st
+            st = out
         return st, en, info
 
     def best(self, want_state: bool = True):
@@ -164,6 +183,10 @@ class Problem:
         _lib.check(_lib.load().mi_sa_best(
             self._h, C.byref(idx), C.byref(en), C.byref(key),
             st.ctypes.data_as(C.c_void_p) if st is not None else None))
+        if st is not None and self.perm is not None:
+            out = np.empty_like(st)
+            out[self.perm] = st
+            st = out
         return int(idx.value), float(en.value), int(key.value), st
 
 

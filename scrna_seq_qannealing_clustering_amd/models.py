@@ -289,6 +289,49 @@ def qubo_dict_to_model(Q: Dict[Tuple[Hashable, Hashable], float], offset: float 
                      info={"kind": "dict"})
 
 
+def slot_independent_order(rowptr: np.ndarray, col: np.ndarray, slot: int = 64) -> np.ndarray:
+    """Sweep order for the structured kernels: a permutation ``perm`` (``perm[new] = old``) that packs the
+    variables into consecutive blocks of ``slot`` (the wavefront width) such that, as far as a greedy
+    balanced colouring manages, no two variables of a block are neighbours.  Inside such a block the
+    decisions of a sweep interact only through the global sum, which the kernel exploits (integer fast
+    path); blocks that keep an internal edge simply take the general path.  Any visiting order is a valid
+    Metropolis sweep; this one is deterministic (degree-descending greedy, ties by index)."""
+    rowptr = np.asarray(rowptr)
+    col = np.asarray(col)
+    n = len(rowptr) - 1
+    nslots = (n + slot - 1) // slot
+    if nslots <= 1:
+        return np.arange(n, dtype=np.int64)
+    cap = np.full(nslots, slot, dtype=np.int64)
+    cap[-1] = n - slot * (nslots - 1)
+    fill = np.zeros(nslots, dtype=np.int64)
+    where = np.full(n, -1, dtype=np.int64)
+    deg = np.diff(rowptr)
+    big = np.int64(1) << 40
+    for v in np.argsort(-deg, kind="stable"):
+        key = fill * nslots + np.arange(nslots)              # least filled first, ties by slot index
+        key = np.where(fill >= cap, 4 * big, key)            # full slots are never chosen
+        nb = where[col[rowptr[v]:rowptr[v + 1]]]
+        key[nb[nb >= 0]] += big                              # slots holding a neighbour: only as a last resort
+        s = int(np.argmin(key))
+        where[v] = s
+        fill[s] += 1
+    return np.lexsort((np.arange(n), where)).astype(np.int64)   # by slot, then by original index
+
+
+def permute_csr(rowptr, col, val, perm):
+    """CSR of the same symmetric matrix with variables renumbered by ``perm`` (``perm[new] = old``); rows keep
+    their neighbours in ascending NEW index order."""
+    n = len(perm)
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    rows_old = np.repeat(np.arange(n), np.diff(rowptr))
+    r_new, c_new = inv[rows_old], inv[np.asarray(col)]
+    order = np.lexsort((c_new, r_new))
+    out_ptr = np.concatenate([[0], np.cumsum(np.bincount(r_new, minlength=n))]).astype(np.int32)
+    return out_ptr, c_new[order].astype(np.int32), np.asarray(val)[order]
+
+
 def add_size_window_penalty(model: QuboModel, lb: float, ub: float, lagrange_multiplier: float,
                             slack_prefix: str = "slack_c1_constraint_") -> QuboModel:
     """Penalty form of ``bqm.add_linear_inequality_constraint([(x_i, 1)...], lb, ub, lagrange)``

@@ -230,7 +230,7 @@ class MI355XSampler:
         if use_csr:
             prob = Problem.csr_rank1(model.rowptr, model.col, model.val.astype(np.float32),
                                      model.lin.astype(np.float32), float(np.float32(model.c_pair)),
-                                     offset=model.offset, device=self.device)
+                                     offset=model.offset, device=self.device, order="slots")
         else:
             prob = Problem.dense(_symmetric_f32(model.dense_Qs()), offset=model.offset,
                                  device=self.device)

@@ -133,6 +133,34 @@ def test_csr_rank1_large_models(n, R, sweeps):
     assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
 
 
+def test_csr_rank1_slot_independent_order_and_integer_fast_path():
+    """order="slots" renumbers the variables so that a wavefront's 64 variables are mutually non-adjacent;
+    such slots take the kernel's integer fast path (the accept rule of every lane as a bound on sum(x), found
+    by bisecting the exact fp32 predicate).  The run equals the oracle on the SAME renumbered model, flip for
+    flip, and states come back in the caller's order.  Hot and cold schedules, both signs of c_pair."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(900, 5, 15, 15, 5, seed=4)
+    m = models.build_bqm_qubo(graphs.EdgeListGraph(nodes, eu, ev, w), 0.05)
+    perm = models.slot_independent_order(m.rowptr, m.col)
+    rp, cc, vv = models.permute_csr(m.rowptr, m.col, m.val, perm)
+    rows = np.repeat(np.arange(900), np.diff(rp))
+    assert not np.any((rows >> 6) == (cc >> 6))                  # no edge inside any 64-block
+    init = np.random.RandomState(1).randint(0, 2, size=(40, 900)).astype(np.uint8)
+    for c_pair, betas in ((float(np.float32(m.c_pair)), np.geomspace(1e-3, 30.0, 25)),
+                          (-float(np.float32(m.c_pair)), np.geomspace(1e-4, 0.5, 10)),
+                          (0.0, np.geomspace(1e-2, 5.0, 10))):
+        ost, oen, ostats = so.sa_csr_rank1_philox(rp, cc, f32(vv), f32(m.lin[perm]), c_pair, 40, betas, 8,
+                                                  init=np.ascontiguousarray(init[:, perm]))
+        with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), c_pair, order="slots") as p:
+            p.anneal(40, betas, 8, initial_states=init)
+            st, en, info = p.fetch()
+            idx, e_best, key, s_best = p.best()
+        assert info["accepted"] == int(ostats[1]) and info["accepted"] > 0
+        assert np.array_equal(st[:, perm], ost)
+        assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+        assert np.array_equal(s_best, st[idx])
+
+
 def test_csr_rank1_hot_schedule_and_launch_shapes():
     """Many flips per slot (a schedule that starts at ~100 % acceptance) and in-slot neighbour updates, for
     every workgroup shape: the chain does not depend on how replicas are packed into workgroups."""
