@@ -174,16 +174,33 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(Ell
                 const int lo = down ? -64 : -Ji;                          // accepts iff lo <= s - s0 <= lo + width
                 const unsigned int width = (unsigned int)(Ji + 64);
                 K2_TICK(t_pre);
-                int dS = 0;
-                while (true) {
-                    const uint64_t m = __ballot((unsigned int)(dS - lo) <= width) & todo;
-                    if (m == 0) break;
-                    const int l = __ffsll((unsigned long long)m) - 1;
-                    todo = (~0ull << l) << 1;
-                    flipped |= 1ull << l;
-                    dS += ((xm_t >> l) & 1ull) ? -1 : 1;
-                }
-                S += dS;
+                // The serial loop, hand-scheduled: with four wavefronts per SIMD it is bound by SCALAR issue (one
+                // SALU instruction per SIMD every four cycles), and hipcc spends 16 scalar instructions per flip
+                // on it.  Here: 5 SALU + 3 VALU.  q = (s - s0) - lo per lane; the flipped lane's +-1 reaches
+                // every lane through v_readlane; todo = lanes above the last flipped one.
+                unsigned int q = (unsigned int)(0 - lo);
+                const int delta = xi ? -1 : 1;
+                uint64_t m;
+                int l_s, d_s;
+                asm volatile(
+                    "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
+                    "s_and_b64 %[m], vcc, %[todo]\n\t"
+                    "s_cbranch_scc0 1f\n"
+                    "0:\n\t"
+                    "s_ff1_i32_b64 %[l], %[m]\n\t"
+                    "s_lshl_b64 %[todo], -2, %[l]\n\t"
+                    "s_bitset1_b64 %[fl], %[l]\n\t"
+                    "s_nop 1\n\t"                                      // SALU-written lane select: 4 wait states
+                    "v_readlane_b32 %[d], %[delta], %[l]\n\t"
+                    "v_add_u32 %[q], %[q], %[d]\n\t"
+                    "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
+                    "s_and_b64 %[m], vcc, %[todo]\n\t"
+                    "s_cbranch_scc1 0b\n"
+                    "1:\n\t"
+                    : [q] "+v"(q), [todo] "+s"(todo), [fl] "+s"(flipped), [m] "=&s"(m), [l] "=&s"(l_s), [d] "=&s"(d_s)
+                    : [w] "v"(width), [delta] "v"(delta)
+                    : "vcc", "scc");
+                S += __popcll(flipped & ~xm_t) - __popcll(flipped & xm_t);
             } else {
                 float Sf = (float)(S - (int)xi);
                 // wait for this slot's small loads HERE (a counted wait that leaves the prefetch in flight): left
