@@ -100,6 +100,8 @@ struct mi_sa_problem {
     float *d_ell_val = nullptr, *d_lin = nullptr;
     uint2 *d_rows = nullptr;                 // K2: row-major adjacency, in-slot neighbours first
     uint32_t *d_meta = nullptr;              // K2: in-slot count | degree << 8
+    uint4 *d_adj4 = nullptr;                 // K2: packed slot adjacency (see EllArgs::adj4)
+    uint32_t *d_slot_flags = nullptr;        // K2: slots with internal edges
     int cus = 0;
     // run buffers
     int cap_R = 0, cap_sweeps = 0;
@@ -345,6 +347,28 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
         HIP_TRY(hipMalloc((void **)&p->d_meta, hm.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(p->d_rows, hr.data(), hr.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_meta, hm.data(), hm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (p->kind == MI_KIND_CSR_RANK1) {
+            // K2's register image of a slot: groups of four (neighbour, value) per lane, the neighbour already
+            // translated into where its state bit lives in LDS (the state masks start at LDS address 0)
+            const int G = D / 4;
+            std::vector<uint32_t> ha((size_t)slots * G * 2 * 64 * 4, 0u), hf((size_t)slots, 0u);
+            for (int t = 0; t < slots; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    if (hm[(size_t)t * 64 + lane] & 0xffu) hf[t] = 1u;
+                    for (int k = 0; k < D; ++k) {
+                        const uint32_t c = hc[((size_t)t * D + k) * 64 + lane];
+                        uint32_t vb;
+                        memcpy(&vb, &hv[((size_t)t * D + k) * 64 + lane], 4);
+                        const size_t base = (((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3);
+                        ha[base] = (((c >> 5) * 4u) << 8) | (c & 31u);
+                        ha[base + 256] = vb;
+                    }
+                }
+            HIP_TRY(hipMalloc((void **)&p->d_adj4, ha.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void **)&p->d_slot_flags, hf.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(p->d_adj4, ha.data(), ha.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->d_slot_flags, hf.data(), hf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
     }
     return MI_OK;
 }
@@ -400,7 +424,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_rows, p->d_meta, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -504,7 +528,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         a.resync = resync_interval; a.slots = p->slots; a.D = p->D;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
-        a.rows = p->d_rows; a.meta = p->d_meta; a.waves_override = p->opt_k2_waves;
+        a.rows = p->d_rows; a.meta = p->d_meta; a.adj4 = p->d_adj4; a.slot_flags = p->d_slot_flags; a.waves_override = p->opt_k2_waves;
         if (p->kind == MI_KIND_POTTS_CSR && init) {
             // labels must be < K: validated on the host copy (the device trusts them as cnt[] indices)
             const uint16_t *l = static_cast<const uint16_t *>(init);

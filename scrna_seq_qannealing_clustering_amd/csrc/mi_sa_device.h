@@ -225,7 +225,10 @@ struct EllArgs {
     // K2: row-major copy of the adjacency with the neighbours inside the variable's own 64-slot first
     const uint2 *rows;         // [slots*64][D] (col, val bits), padding (self, +0)
     const uint32_t *meta;      // per variable: in-slot neighbour count | degree << 8
-    int waves_override;        // K2: replicas per workgroup (0 = default)
+    const uint4 *adj4;         // K2: per slot, per group of 4 entries: [64][4] packed neighbours (LDS byte offset of
+                               // the neighbour's 32-bit state word << 8 | bit), then [64][4] values
+    const uint32_t *slot_flags;// K2: per slot, non-zero when some variable of the slot has an in-slot neighbour
+    int waves_override;        // (unused)
 };
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_potts(const EllArgs &, hipStream_t);

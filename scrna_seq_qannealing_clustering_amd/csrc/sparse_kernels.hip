@@ -52,17 +52,17 @@ __device__ __forceinline__ void slot_words(uint32_t (&w)[4], int tg, int lane, u
 #endif
 
 template <int D>
-__global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllArgs a)
+__global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllArgs a)
 {
+    // ONE wavefront per workgroup: the replica's state masks start at LDS address 0, so the host can store
+    // every neighbour as a ready-made (LDS byte offset of its 32-bit state word << 8 | bit position).
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = blockIdx.x * (int)(blockDim.x >> 6) + wave;
-    if (r >= a.R) return;                                   // no workgroup-level synchronisation below
+    const int r = blockIdx.x;
+    if (r >= a.R) return;
     const uint32_t gid = a.replica_offset + (uint32_t)r;
     const int n = a.n, slots = a.slots;
-    uint64_t *xm = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * slots;   // bit l of xm[t] = x[64 t + l]
-    const uint32_t *xw = reinterpret_cast<const uint32_t *>(xm);                // the same bits as 32-bit words
+    uint64_t *xm = reinterpret_cast<uint64_t *>(lds);                          // bit l of xm[t] = x[64 t + l]
     const uint8_t *init = static_cast<const uint8_t *>(a.init);
     const uint2 *rows = a.rows;
 
@@ -89,19 +89,29 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(Ell
         }
     }
 
-    // The slot's adjacency does not depend on the chain: with D = 16 it is fetched one slot ahead (double
-    // buffered in registers); wider rows are fetched at the slot start and hidden by the other wavefronts.
-    constexpr bool PF = (D == 16);
-    struct SlotAdj { uint32_t col[D]; float val[D]; float lin; };
+    // The slot's adjacency does not depend on the chain: it is fetched one slot ahead into one of two register
+    // buffers (the slot loop is unrolled by two, so no copies) with D/2 buffer_load_dwordx4 whose addresses
+    // cost no VALU work: descriptor + (lane*16) + scalar slot offset + immediate.
+    //   adj4 layout per slot: for g < D/4: [64 lanes][4] packed neighbours, then [64 lanes][4] values.
+    constexpr int G = D / 4;
+    const __amdgpu_buffer_rsrc_t rs_adj = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(a.adj4), 0, slots * G * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.lin), 0, slots * 256, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_flag = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(a.slot_flags), 0, slots * 4, 0x00020000);
+    struct SlotAdj { u32x4 col[G]; u32x4 val[G]; uint32_t lin, flag; };
     auto fetch_adj = [&](int t) {
         SlotAdj p;
         const int tt = t < slots ? t : slots - 1;
+        const int soff = tt * (G * 2048);
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            p.col[k] = a.ell_col[((size_t)tt * D + k) * 64 + lane];
-            p.val[k] = a.ell_val[((size_t)tt * D + k) * 64 + lane];
+        for (int g = 0; g < G; ++g) {
+            p.col[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16, soff + g * 2048, 0);
+            p.val[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16, soff + g * 2048 + 1024, 0);
         }
-        p.lin = a.lin[(size_t)tt * 64 + lane];
+        p.lin = __builtin_amdgcn_raw_buffer_load_b32(rs_lin, lane * 4, tt * 256, 0);
+        p.flag = __builtin_amdgcn_raw_buffer_load_b32(rs_flag, 0, tt * 4, 0);   // arrives with the prefetch: no stall
         return p;
     };
 
@@ -109,138 +119,159 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(Ell
 #ifdef MI_K2_PROFILE
     unsigned long long tick_ = __builtin_amdgcn_s_memtime(), t_pre = 0, t_loop = 0, t_wait = 0, t_apply = 0, t_init = 0;
 #endif
-    for (int s = 0; s < a.num_sweeps; ++s) {
-        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
-            __float_as_int(a.temps[a.temps_per_replica ? r : s])));
-        SlotAdj nxt;
-        if constexpr (PF) nxt = fetch_adj(0);
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll 1
-        for (int t = 0; t < slots; ++t) {                    // ONE copy of the slot body (instruction cache)
-            if ((t & 3) == 0)
-                slot_words(w, t >> 2, lane, (uint32_t)s + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
-            const int c = t & 3;
-            const uint32_t wc = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
-            const int i = t * 64 + lane;
-            // needed only after the field sum below, which hides their latency; issued BEFORE the prefetch of
-            // the next slot so that waiting for them (loads return in order) does not wait for the prefetch
-            const uint32_t metav = a.meta[i];
-            const uint4 e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D);
-            const uint4 e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D + 2);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    float T = 1.0f;
+    int s = 0;
+
+    auto slot_body = [&](int t, const SlotAdj &cur) {
+        if ((t & 3) == 0)
+            slot_words(w, t >> 2, lane, (uint32_t)s + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
+        const int c = t & 3;
+        const uint32_t wc = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
+        const int i = t * 64 + lane;
+        const bool general = __builtin_amdgcn_readfirstlane((int)cur.flag) != 0;   // some variable of this slot has a
+        uint32_t metav = 0u;                                  // neighbour inside the slot
+        uint4 e01 = make_uint4(0u, 0u, 0u, 0u), e23 = e01;
+        if (general) {
+            metav = a.meta[i];
+            e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D);
+            e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D + 2);
+        }
+        K2_TICK(t_init);
+        // fresh field: lin_i + the stored neighbours whose bit is set, in stored order.  A clear bit adds +0.0f
+        // (value AND mask): x + 0.0f == x for every x except -0.0f, and +-0.0f are the same number to every
+        // comparison downstream -- no decision can differ from the oracle's skip.
+        float gi = __uint_as_float(cur.lin);
+#pragma unroll
+        for (int g0 = 0; g0 < G; g0 += 4) {                   // 16 state words in flight, then 16 adds
+            uint32_t word[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                word[k] = *reinterpret_cast<const uint32_t *>(lds + (cur.col[g0 + k / 4][k & 3] >> 8));
             asm volatile("" ::: "memory");
-            SlotAdj cur;
-            if constexpr (PF) { cur = nxt; nxt = fetch_adj(t + 1); } else { cur = fetch_adj(t); }
-            K2_TICK(t_init);
-            // fresh field: lin_i + sum over the stored neighbours whose bit is set, in stored order
-            // (x + 0.0f == x for every x the sum can hold except -0.0f, which compares equal anyway: the
-            // select form below is exact without that caveat)
-            float gi = cur.lin;
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const uint32_t cc = cur.col[k];
-                const uint32_t bit = (xw[cc >> 5] >> (cc & 31u)) & 1u;
-                const float sum = gi + cur.val[k];
-                gi = bit ? sum : gi;
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t pk = cur.col[g0 + k / 4][k & 3];
+                const int msk = -(int)((word[k] >> (pk & 31u)) & 1u);
+                gi = gi + __uint_as_float(cur.val[g0 + k / 4][k & 3] & (uint32_t)msk);
             }
-            K2_TICK(t_apply);
-            float thr = neglog_u(wc) * T;
-            if (i >= n) thr = -INFINITY;
-            const uint64_t xm_v = xm[t];                     // same word in every lane: make it scalar
-            const uint64_t xm_t = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xm_v >> 32)) << 32) |
-                                  (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xm_v);
-            const uint32_t xi = (uint32_t)((xm_t >> lane) & 1ull);
-            const uint32_t sgnbit = xi << 31;                // dE = x ? -f : f
-            const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
-            uint64_t todo = ~0ull, flipped = 0ull;
-            if (has_in == 0ull) {
-                // ---- no variable of this slot has a neighbour inside it: decisions depend on s alone --------
-                // dE_i(u) = +-(g_i + c*u), u = (float)(s - x_i), is monotone in u (fp32 rounding is monotone), so
-                // "lane i accepts" is a half-line in s.  Its end point is found by bisecting the EXACT fp32
-                // predicate over the 127 values s can take inside this slot (|s - s0| <= 63), and the serial
-                // loop becomes integer: two VALU instructions per accepted flip instead of nine.
-                const bool down = (a.c_pair >= 0.0f) == (xi == 0u);       // accepts for SMALL s (else for large s)
-                const float sig = down ? 1.0f : -1.0f;
-                const float u0 = (float)(S - (int)xi);
-                float J = -64.0f;                                         // accepts iff sig*(s - s0) <= J
+        }
+        K2_TICK(t_apply);
+        float thr = neglog_u(wc) * T;
+        if (i >= n) thr = -INFINITY;
+        const uint64_t xm_v = xm[t];                          // same word in every lane: make it scalar
+        const uint64_t xm_t = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xm_v >> 32)) << 32) |
+                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xm_v);
+        const uint32_t xi = (uint32_t)((xm_t >> lane) & 1ull);
+        const uint32_t sgnbit = xi << 31;                     // dE = x ? -f : f
+        uint64_t todo = ~0ull, flipped = 0ull;
+        if (!general) {
+            // ---- no variable of this slot has a neighbour inside it: decisions depend on s alone -------------
+            // dE_i(u) = +-(g_i + c*u), u = (float)(s - x_i), is monotone in u (fp32 rounding is monotone), so
+            // "lane i accepts" is a half-line in s.  Its end point is found by bisecting the EXACT fp32
+            // predicate over the 127 values s can take inside this slot (|s - s0| <= 63), and the serial loop
+            // becomes integer.  The sign of the move is folded into both operands (negation is exact):
+            //     dE(u) = gs + cs*u,  gs = +-g_i, cs = +-c;  non-decreasing in u iff cs >= 0.
+            const float gs = __uint_as_float(__float_as_uint(gi) ^ sgnbit);
+            const float cs = __uint_as_float(__float_as_uint(a.c_pair) ^ sgnbit);
+            const float sig = (cs < 0.0f) ? -1.0f : 1.0f;     // accepts iff sig*(s - s0) <= J
+            const float u0 = (float)(S - (int)xi);
+            float U = __fmaf_rn(sig, -64.0f, u0);             // "never": one below the window
 #pragma unroll
-                for (int step = 64; step >= 1; step >>= 1) {
-                    const float cand = J + (float)step;
-                    const float u = __fmaf_rn(sig, cand, u0);             // small integers: exact
-                    const float fi = gi + a.c_pair * u;
-                    const float dE = __uint_as_float(__float_as_uint(fi) ^ sgnbit);
-                    J = (dE < thr) ? cand : J;
-                }
-                const int Ji = (int)J;
-                const int lo = down ? -64 : -Ji;                          // accepts iff lo <= s - s0 <= lo + width
-                const unsigned int width = (unsigned int)(Ji + 64);
-                K2_TICK(t_pre);
-                // The serial loop, hand-scheduled: with four wavefronts per SIMD it is bound by SCALAR issue (one
-                // SALU instruction per SIMD every four cycles), and hipcc spends 16 scalar instructions per flip
-                // on it.  Here: 5 SALU + 3 VALU.  q = (s - s0) - lo per lane; the flipped lane's +-1 reaches
-                // every lane through v_readlane; todo = lanes above the last flipped one.
-                unsigned int q = (unsigned int)(0 - lo);
-                const int delta = xi ? -1 : 1;
-                uint64_t m;
-                int l_s, d_s;
-                asm volatile(
-                    "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
-                    "s_and_b64 %[m], vcc, %[todo]\n\t"
-                    "s_cbranch_scc0 1f\n"
-                    "0:\n\t"
-                    "s_ff1_i32_b64 %[l], %[m]\n\t"
-                    "s_lshl_b64 %[todo], -2, %[l]\n\t"
-                    "s_bitset1_b64 %[fl], %[l]\n\t"
-                    "s_nop 1\n\t"                                      // SALU-written lane select: 4 wait states
-                    "v_readlane_b32 %[d], %[delta], %[l]\n\t"
-                    "v_add_u32 %[q], %[q], %[d]\n\t"
-                    "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
-                    "s_and_b64 %[m], vcc, %[todo]\n\t"
-                    "s_cbranch_scc1 0b\n"
-                    "1:\n\t"
-                    : [q] "+v"(q), [todo] "+s"(todo), [fl] "+s"(flipped), [m] "=&s"(m), [l] "=&s"(l_s), [d] "=&s"(d_s)
-                    : [w] "v"(width), [delta] "v"(delta)
-                    : "vcc", "scc");
-                S += __popcll(flipped & ~xm_t) - __popcll(flipped & xm_t);
-            } else {
-                float Sf = (float)(S - (int)xi);
-                // wait for this slot's small loads HERE (a counted wait that leaves the prefetch in flight): left
-                // to hipcc the wait lands at their first use inside the loop
-                asm volatile("" ::"v"(metav), "v"(e01.x), "v"(e01.y), "v"(e01.z), "v"(e01.w), "v"(e23.x), "v"(e23.y),
-                             "v"(e23.z), "v"(e23.w));
-                K2_TICK(t_pre);
-                while (true) {
-                    const float fi = gi + a.c_pair * Sf;
-                    const float dE = __uint_as_float(__float_as_uint(fi) ^ sgnbit);
-                    const uint64_t m = __ballot(dE < thr) & todo;
-                    if (m == 0) break;
-                    const int l = __ffsll((unsigned long long)m) - 1;
-                    todo = (~0ull << l) << 1;
-                    flipped |= 1ull << l;
-                    const bool xl = (xm_t >> l) & 1ull;          // the lane's bit BEFORE its (only) flip in this slot
-                    const float sgn = xl ? -1.0f : 1.0f;
-                    S += xl ? -1 : 1;
-                    Sf += sgn;
-                    if ((has_in >> l) & 1ull) {                  // wave-uniform: l has neighbours inside this slot
-                        const int nin = (int)(__builtin_amdgcn_readlane((int)metav, l) & 0xff);
-                        auto hit = [&](uint32_t cc, uint32_t vv) {
-                            if (lane == (int)(cc & 63u)) gi = gi + sgn * __uint_as_float(vv);
-                        };
-                        hit(__builtin_amdgcn_readlane((int)e01.x, l), __builtin_amdgcn_readlane((int)e01.y, l));
-                        if (nin > 1) hit(__builtin_amdgcn_readlane((int)e01.z, l), __builtin_amdgcn_readlane((int)e01.w, l));
-                        if (nin > 2) hit(__builtin_amdgcn_readlane((int)e23.x, l), __builtin_amdgcn_readlane((int)e23.y, l));
-                        if (nin > 3) hit(__builtin_amdgcn_readlane((int)e23.z, l), __builtin_amdgcn_readlane((int)e23.w, l));
-                        for (int k = 4; k < nin; ++k) {
-                            const uint2 e = rows[((size_t)t * 64 + l) * D + k];
-                            hit(e.x, e.y);
-                        }
+            for (int step = 64; step >= 1; step >>= 1) {
+                const float Uc = __fmaf_rn(sig, (float)step, U);      // small integers: exact
+                const float dE = gs + cs * Uc;
+                U = (dE < thr) ? Uc : U;
+            }
+            const int Ji = (int)(sig * (U - u0));             // in [-64, 63]
+            const int lo = (cs < 0.0f) ? -Ji : -64;           // accepts iff lo <= s - s0 <= lo + width
+            const unsigned int width = (unsigned int)(Ji + 64);
+            K2_TICK(t_pre);
+            // The serial loop, hand-scheduled: with four wavefronts per SIMD it is bound by SCALAR issue (one
+            // SALU instruction per SIMD every four cycles), and hipcc spends 16 scalar instructions per flip
+            // on it.  Here: 5 SALU + 3 VALU.  q = (s - s0) - lo per lane; the flipped lane's +-1 reaches
+            // every lane through v_readlane; todo = lanes above the last flipped one.
+            unsigned int q = (unsigned int)(0 - lo);
+            const int delta = xi ? -1 : 1;
+            uint64_t m;
+            int l_s, d_s;
+            asm volatile(
+                "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
+                "s_and_b64 %[m], vcc, %[todo]\n\t"
+                "s_cbranch_scc0 1f\n"
+                "0:\n\t"
+                "s_ff1_i32_b64 %[l], %[m]\n\t"
+                "s_lshl_b64 %[todo], -2, %[l]\n\t"
+                "s_bitset1_b64 %[fl], %[l]\n\t"
+                "s_nop 1\n\t"                                  // SALU-written lane select: 4 wait states
+                "v_readlane_b32 %[d], %[delta], %[l]\n\t"
+                "v_add_u32 %[q], %[q], %[d]\n\t"
+                "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
+                "s_and_b64 %[m], vcc, %[todo]\n\t"
+                "s_cbranch_scc1 0b\n"
+                "1:\n\t"
+                : [q] "+v"(q), [todo] "+s"(todo), [fl] "+s"(flipped), [m] "=&s"(m), [l] "=&s"(l_s), [d] "=&s"(d_s)
+                : [w] "v"(width), [delta] "v"(delta)
+                : "vcc", "scc");
+            S += __popcll(flipped & ~xm_t) - __popcll(flipped & xm_t);
+        } else {
+            const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
+            float Sf = (float)(S - (int)xi);
+            K2_TICK(t_pre);
+            while (true) {
+                const float fi = gi + a.c_pair * Sf;
+                const float dE = __uint_as_float(__float_as_uint(fi) ^ sgnbit);
+                const uint64_t m = __ballot(dE < thr) & todo;
+                if (m == 0) break;
+                const int l = __ffsll((unsigned long long)m) - 1;
+                todo = (~0ull << l) << 1;
+                flipped |= 1ull << l;
+                const bool xl = (xm_t >> l) & 1ull;           // the lane's bit BEFORE its (only) flip in this slot
+                const float sgn = xl ? -1.0f : 1.0f;
+                S += xl ? -1 : 1;
+                Sf += sgn;
+                if ((has_in >> l) & 1ull) {                   // wave-uniform: l has neighbours inside this slot
+                    const int nin = (int)(__builtin_amdgcn_readlane((int)metav, l) & 0xff);
+                    auto hit = [&](uint32_t cc, uint32_t vv) {
+                        if (lane == (int)(cc & 63u)) gi = gi + sgn * __uint_as_float(vv);
+                    };
+                    hit(__builtin_amdgcn_readlane((int)e01.x, l), __builtin_amdgcn_readlane((int)e01.y, l));
+                    if (nin > 1) hit(__builtin_amdgcn_readlane((int)e01.z, l), __builtin_amdgcn_readlane((int)e01.w, l));
+                    if (nin > 2) hit(__builtin_amdgcn_readlane((int)e23.x, l), __builtin_amdgcn_readlane((int)e23.y, l));
+                    if (nin > 3) hit(__builtin_amdgcn_readlane((int)e23.z, l), __builtin_amdgcn_readlane((int)e23.w, l));
+                    for (int k = 4; k < nin; ++k) {
+                        const uint2 e = rows[((size_t)t * 64 + l) * D + k];
+                        hit(e.x, e.y);
                     }
                 }
             }
-            if (flipped) {                                   // wave-uniform
-                accepted += (unsigned long long)__popcll(flipped);
-                if (lane == 0) xm[t] = xm_t ^ flipped;
+        }
+        if (flipped) {                                        // wave-uniform
+            accepted += (unsigned long long)__popcll(flipped);
+            if (lane == 0) xm[t] = xm_t ^ flipped;
+        }
+        K2_TICK(t_loop);
+    };
+
+    for (s = 0; s < a.num_sweeps; ++s) {
+        T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[a.temps_per_replica ? r : s])));
+        if constexpr (D == 16) {
+            SlotAdj A = fetch_adj(0), B;
+#pragma unroll 1
+            for (int t = 0; t < slots; t += 2) {
+                B = fetch_adj(t + 1);
+                slot_body(t, A);
+                if (t + 1 < slots) {                          // wave-uniform
+                    A = fetch_adj(t + 2);
+                    slot_body(t + 1, B);
+                }
             }
-            K2_TICK(t_loop);
+        } else {                                              // wide rows: one buffer, hidden by the other waves
+#pragma unroll 1
+            for (int t = 0; t < slots; ++t) {
+                const SlotAdj A = fetch_adj(t);
+                slot_body(t, A);
+            }
         }
     }
 #ifdef MI_K2_PROFILE
@@ -452,17 +483,13 @@ int launch_sparse(KernelT kernel, const EllArgs &a, size_t lds_per_wave, hipStre
 template <typename KernelT>
 int launch_csr_rank1(KernelT kernel, const EllArgs &a, hipStream_t st)
 {
-    // the only per-replica LDS is the state mask (8 bytes per slot): 4 replicas per workgroup, as many
-    // workgroups per CU as registers allow; fewer replicas per workgroup only when the masks are huge
-    int waves = a.waves_override > 0 ? a.waves_override : kSparseWaves;
-    if (waves > 4) waves = 4;
-    const size_t per_wave = (size_t)a.slots * 8;
-    while (waves > 1 && per_wave * waves > 160 * 1024) --waves;
-    const size_t lds = per_wave * waves;
+    // one wavefront = one replica = one workgroup; the only LDS is the state mask (8 bytes per slot)
+    const size_t lds = (size_t)a.slots * 8;
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1: n = %d exceeds the state-mask LDS budget", a.n);
+    if (!a.adj4 || !a.slot_flags) return fail(MI_EHIP, "csr_rank1: packed adjacency missing");
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((a.R + waves - 1) / waves), dim3(waves * 64), lds, st, a);
+    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
