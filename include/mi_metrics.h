@@ -1,0 +1,41 @@
+/*
+ * mi_metrics.h -- C ABI of the cluster-quality metrics on MI355X (part of libmi_sa.so).
+ *
+ * The step immediately AFTER the clustering path: the only numbers the
+ * reference publishes come from it.  In the reference it is R:
+ *     /root/reference/R/pbmc3k/Pbmc3k_benchmark_clusters.Rmd:36,47,69   mean(proxy::dist(cells, "jaccard")) per cluster
+ *     :82-94     cluster::silhouette(labels, proxy::dist(cells, "jaccard"))
+ *     :98-112    fpc::cluster.stats(dist, labels)  ->  R/pbmc3k/QA_benchmark.csv, Seurat_benchmark.csv, Kmeans_benchmark.csv
+ * mi_jaccard_cluster_stats replaces the O(n^2 g) part of all three: one pass over all pairs of cells that
+ * never materialises the n x n distance matrix (unless asked to) and returns the sufficient statistics
+ * every one of those numbers is a closed form of (scrna_seq_qannealing_clustering_amd/metrics.py).
+ *
+ * Distances: binary Jaccard d = 1 - |A & B| / |A | B| on the non-zero pattern of each cell's gene row,
+ * evaluated in fp64 (two empty rows: 0).  Conventions as in mi_sa.h.
+ */
+#ifndef MI_METRICS_H
+#define MI_METRICS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bits: n x words uint64, bit b of word w of row i = (gene 64 w + b is expressed in cell i); labels in [0, K),
+ * K <= 64, words <= 200.  Outputs (host, caller-allocated):
+ *   rowsum       n x K   sum over j != i with label c of d(i, j)
+ *   rowsq_all    n       sum over j != i of d(i, j)^2
+ *   rowsq_within n       the same restricted to j in i's cluster
+ *   diameter     K       max d inside cluster c (0 for singletons)
+ *   separation   K x K   min d between clusters c, c' (+inf where a cluster is empty; diagonal 0)
+ *   out_D        n x n fp32 distance matrix, or NULL (nothing n x n is ever allocated then)
+ *   out_kernel_ms        device time of the pass, or NULL */
+int mi_jaccard_cluster_stats(const uint64_t *bits, int n, int words, const int32_t *labels, int K, int device,
+                             double *rowsum, double *rowsq_all, double *rowsq_within, double *diameter,
+                             double *separation, float *out_D, float *out_kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_METRICS_H */

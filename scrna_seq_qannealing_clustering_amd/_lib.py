@@ -65,6 +65,9 @@ def _declare(lib):
         "mi_snn_fetch": (C.c_int, [vp, i32p, C.POINTER(C.c_int64), i32p, i32p]),
         "mi_snn_kernel_ms": (C.c_int, [vp, f32p, f32p, f32p]),
         "mi_snn_destroy": (C.c_int, [vp]),
+        # include/mi_metrics.h
+        "mi_jaccard_cluster_stats": (C.c_int, [u64p, C.c_int, C.c_int, i32p, C.c_int, C.c_int, f64p, f64p, f64p, f64p,
+                                               f64p, f32p, f32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
@@ -80,6 +83,7 @@ EXPORTS = (
     "mi_sa_set_option", "mi_sa_debug_pace", "mi_sa_debug_stats", "mi_sa_anneal", "mi_sa_anneal_ex", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_last_launch_count", "mi_sa_fetch", "mi_sa_best",
     "mi_sa_qubo_dense_f32", "mi_energy_dense_f32", "mi_energy_dense_f32_ex",
     "mi_snn_build_f32", "mi_snn_info", "mi_snn_fetch", "mi_snn_kernel_ms", "mi_snn_destroy",
+    "mi_jaccard_cluster_stats",
 )
 
 
