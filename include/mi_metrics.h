@@ -23,7 +23,8 @@ extern "C" {
 #endif
 
 /* bits: n x words uint64, bit b of word w of row i = (gene 64 w + b is expressed in cell i); labels in [0, K),
- * K <= 64, words <= 200.  Outputs (host, caller-allocated):
+ * K <= 64, 640 * words + 1024 * K bytes <= 160 KB of LDS (e.g. 12800 genes with 32 clusters).  Outputs (host,
+ * caller-allocated):
  *   rowsum       n x K   sum over j != i with label c of d(i, j)
  *   rowsq_all    n       sum over j != i of d(i, j)^2
  *   rowsq_within n       the same restricted to j in i's cluster
