@@ -77,7 +77,11 @@ int mi_sa_problem_destroy(mi_sa_problem *p);
 int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases, int *device);
 
 /* Tuning switches that never change results: "pace" (default 1) holds the replicas of one XCD together
- * at sweep boundaries so that their Q-row reads share that XCD's L2. */
+ * at sweep boundaries so that their Q-row reads share that XCD's L2.
+ * One MODEL switch: "min_cluster_size" (Potts problems, default 0) -- every cluster keeps at least that many
+ * members: a move out of a cluster holding exactly that many is rejected whatever its energy change.  This
+ * is the `sum_i v[i][j] >= 20` constraint of the reference's CQM (CQM_clustering.py:46-48) as a hard
+ * constraint; initial states must satisfy it. */
 int mi_sa_set_option(mi_sa_problem *p, const char *key, long value);
 
 /* Diagnostic: copies the first `words` pacing words of the last launch (layout in mi_sa.hip). */

@@ -287,11 +287,15 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
  * dE = [h_i(b) + c*cnt_b] - [h_i(a) + c*(cnt_a - 1)],  h_i(q) = sum_{j in N(i), l_j == q} S_ij
  * accepted iff dE < neglog_u(word(i,s,g,0)) * temps[s].  h is recomputed per proposal from the CSR
  * row in stored order (fp32 adds in that order); cnt are integers. */
-int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, float c_pair, int n,
-                         int K, double lin_offset, int R, uint32_t replica_offset, int num_sweeps,
-                         const double *betas, uint64_t seed, const uint16_t *init,
-                         uint16_t *out_labels, double *out_energy, uint64_t *out_stats,
-                         uint32_t sweep_offset, int betas_per_replica)
+/* min_size > 0 restricts the chain to labelings in which every cluster keeps at least min_size members
+ * (the "cluster_size >= 20" constraints of CQM_clustering.py:46-48 as a hard constraint): a move out of a
+ * cluster that holds exactly min_size variables is rejected whatever its dE.  The restricted chain still
+ * satisfies detailed balance on the feasible set; the initial state must be feasible. */
+int orc_potts_csr_philox_min(const int *rowptr, const int *col, const float *val, float c_pair, int n,
+                             int K, double lin_offset, int R, uint32_t replica_offset, int num_sweeps,
+                             const double *betas, uint64_t seed, const uint16_t *init,
+                             uint16_t *out_labels, double *out_energy, uint64_t *out_stats,
+                             uint32_t sweep_offset, int betas_per_replica, int min_size)
 {
     uint64_t tot_prop = 0, tot_acc = 0;
     const int nb = betas_per_replica ? R : num_sweeps;
@@ -323,7 +327,7 @@ int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, fl
                 float dE = eb - ea;
                 float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
                 ++tot_prop;
-                if (dE < thr) {
+                if (dE < thr && cnt[a] - 1 >= min_size) {
                     l[i] = (uint16_t)b;
                     cnt[a]--;
                     cnt[b]++;
@@ -342,6 +346,16 @@ int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, fl
     free(temps);
     if (out_stats) { out_stats[0] += tot_prop; out_stats[1] += tot_acc; }
     return 0;
+}
+
+int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, float c_pair, int n,
+                         int K, double lin_offset, int R, uint32_t replica_offset, int num_sweeps,
+                         const double *betas, uint64_t seed, const uint16_t *init,
+                         uint16_t *out_labels, double *out_energy, uint64_t *out_stats,
+                         uint32_t sweep_offset, int betas_per_replica)
+{
+    return orc_potts_csr_philox_min(rowptr, col, val, c_pair, n, K, lin_offset, R, replica_offset, num_sweeps, betas,
+                                    seed, init, out_labels, out_energy, out_stats, sweep_offset, betas_per_replica, 0);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -227,3 +227,53 @@ def clustering_dqm(G, num_of_clusters, gamma, sampler=None, sampler_kwargs: Opti
     if verbose:
         print("Energy: {}\nSolution: {}".format(sampleset.first.energy, sampleset.first.sample))   # :46
     return sampleset
+
+
+def clustering_cqm(G, num_of_clusters, min_cluster_size: int = 20, sampler=None,
+                   sampler_kwargs: Optional[dict] = None, verbose=False):
+    """`clustering_cqm` (CQM_clustering.py:26-55): one-hot k-way model whose objective keeps heavy edges
+    inside clusters, every cluster holding at least 20 cells.  The reference builds n*K binaries plus n + K
+    constraints for the Leap hybrid CQM solver; here the one-hot constraints are the state space itself
+    (one label per node) and the size constraints restrict the moves, so every returned sample is feasible.
+    ``one_hot_sample(sampleset.first.sample, K)`` gives the reference's ``v_{i},{k}`` dictionary."""
+    from .models import build_cqm_potts
+    model = build_cqm_potts(G, num_of_clusters, min_cluster_size)     # :33-48
+    kw = dict(label='CQM - scRAN-seq')                                # :53
+    kw.update(sampler_kwargs or {})
+    sampleset = _sampler(sampler).sample_dqm(model, **kw)
+    if verbose:
+        print("Energy: {}\nSolution: {}".format(sampleset.first.energy, sampleset.first.sample))   # :54
+    return sampleset
+
+
+def one_hot_sample(sample, num_of_clusters):
+    """label dict {node: k}  ->  the CQM's binary dict {'v_<node>,<k>': 0/1} (CQM_clustering.py:34)."""
+    return {"v_%s,%d" % (node, k): int(k == lab) for node, lab in sample.items() for k in range(num_of_clusters)}
+
+
+def graph_subsampling(G, gamma, solver="mi355x", sampler=None, sampler_kwargs: Optional[dict] = None):
+    """`graph_subsampling` (QA_subsampling.py:25-96): the pruning QUBO, solved, ``label1`` written to the nodes
+    (1 = kept)."""
+    from .models import build_subsampling_qubo
+    kw = dict(label="prun_data", chain_strength=4, num_reads=100)     # :37-38,42,56
+    kw.update(sampler_kwargs or {})
+    response = _sampler(sampler).sample_qubo(build_subsampling_qubo(G, gamma), **kw)
+    lut = response.first.sample                                       # :80
+    for node in G.nodes:                                              # :83-94
+        G.nodes[node]["label1"] = 1 if lut[node] else 0
+    return response
+
+
+def graph_subsampling_2(G, gamma=None, sampler=None, sampler_kwargs: Optional[dict] = None, lagrange: float = 2.0):
+    """`graph_subsampling_2` (QA_subsampling.py:98-118): a maximum independent set through the sampler, as
+    ``dnx.maximum_independent_set(G, sampler=...)`` does it; returns the node list S and writes ``label1``."""
+    from .models import build_mis_qubo
+    kw = dict(num_reads=10, label='graph_subsampling_2', time_limit=3.0)      # :102
+    kw.update(sampler_kwargs or {})
+    response = _sampler(sampler).sample_qubo(build_mis_qubo(G, lagrange), **kw)
+    sample = response.first.sample
+    S = [node for node in G.nodes if sample[node] > 0]
+    inside = set(S)
+    for node in G.nodes:                                              # :110-116
+        G.nodes[node]["label1"] = 1 if node in inside else 0
+    return S

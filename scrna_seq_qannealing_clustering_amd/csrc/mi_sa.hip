@@ -124,6 +124,7 @@ struct mi_sa_problem {
     int cap_fields_R = 0;
     int opt_ondemand_permille = 40;          // K1w: on-demand sweeps below this acceptance (per mille); 0 = always stream
     int opt_debug = 0;                       // DenseArgs::debug (diagnostic timing only; results are wrong)
+    int opt_min_cluster_size = 0;            // K3: hard lower bound on every cluster's size (CQM_clustering.py:46-48)
     int opt_k2_waves = 0;                    // K2: replicas per workgroup (0 = auto)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
@@ -473,6 +474,11 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "debug")) { p->opt_debug = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_waves") && value >= 0 && value <= 16) { p->opt_k2_waves = (int)value; return MI_OK; }
+    if (!strcmp(key, "min_cluster_size") && value >= 0) {
+        if (p->kind != MI_KIND_POTTS_CSR) return fail(MI_EINVAL, "min_cluster_size applies to Potts problems");
+        p->opt_min_cluster_size = (int)value;
+        return MI_OK;
+    }
     if (!strcmp(key, "variant") && value >= 0 && value <= 4) { p->opt_variant = (int)value; return MI_OK; }
     if (!strcmp(key, "unit_rows") && (value == 0 || value == 2 || value == 4)) { p->opt_unit_rows = (int)value; return MI_OK; }
     return fail(MI_EINVAL, "unknown option '%s'", key);
@@ -528,7 +534,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         a.resync = resync_interval; a.slots = p->slots; a.D = p->D;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
-        a.rows = p->d_rows; a.meta = p->d_meta; a.adj4 = p->d_adj4; a.slot_flags = p->d_slot_flags; a.waves_override = p->opt_k2_waves;
+        a.rows = p->d_rows; a.meta = p->d_meta; a.adj4 = p->d_adj4; a.slot_flags = p->d_slot_flags; a.waves_override = p->opt_k2_waves; a.min_size = p->opt_min_cluster_size;
         if (p->kind == MI_KIND_POTTS_CSR && init) {
             // labels must be < K: validated on the host copy (the device trusts them as cnt[] indices)
             const uint16_t *l = static_cast<const uint16_t *>(init);

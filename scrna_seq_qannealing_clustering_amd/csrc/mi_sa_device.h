@@ -229,6 +229,7 @@ struct EllArgs {
                                // the neighbour's 32-bit state word << 8 | bit), then [64][4] values
     const uint32_t *slot_flags;// K2: per slot, non-zero when some variable of the slot has an in-slot neighbour
     int waves_override;        // (unused)
+    int min_size;              // K3: a move out of a cluster with exactly min_size members is rejected (0 = off)
 };
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_potts(const EllArgs &, hipStream_t);

@@ -368,6 +368,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
     };
 
     unsigned long long accepted = 0;
+    const float min_sz = (float)a.min_size;
     for (int s = 0; s < a.num_sweeps && K > 1; ++s) {
         const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
             __float_as_int(a.temps[a.temps_per_replica ? r : s])));
@@ -415,7 +416,8 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                 const float ea = ha + a.c_pair * fa;
                 const float eb = hb + a.c_pair * fb;
                 const float dE = eb - ea;
-                const uint64_t m = __ballot(dE < thr) & todo;
+                // fa = (members of this lane's cluster) - 1: a move may not shrink a cluster below min_size
+                const uint64_t m = __ballot(dE < thr && fa >= min_sz) & todo;
                 if (m == 0) break;
                 const int l = __ffsll((unsigned long long)m) - 1;
                 todo = (~0ull << l) << 1;

@@ -237,6 +237,46 @@ def build_dqm_potts(G, num_of_clusters: int, gamma: float) -> PottsModel:
                       info={"gamma": gamma, "kind": "dqm"})
 
 
+def build_cqm_potts(G, num_of_clusters: int, min_cluster_size: int = 20) -> PottsModel:
+    """`clustering_cqm` -- CQM_clustering.py:30-48 -- in Potts form.  The reference's objective is
+    ``sum_{(i,j) in E} sum_p [v_ip + v_jp - 2 w_ij v_ip v_jp]`` (:40-44) under one-hot ``add_discrete``
+    constraints per node (:36-38): with exactly one case set per node the linear part is the constant
+    ``2 |E|`` and the rest is ``-2 w_ij`` for every edge inside a cluster.  The ``>= 20`` members per cluster
+    constraints (:46-48) are carried as ``info["min_cluster_size"]`` and enforced by the sampler as a hard
+    constraint on the moves (mi_sa.h "min_cluster_size")."""
+    nodes, eu, ev, w = graph_arrays(G)
+    n = len(nodes)
+    rowptr, col, val = _csr_from_edges(n, eu, ev, -2.0 * w)
+    lin = np.zeros(n, dtype=np.float64)
+    if n:
+        lin[0] = 2.0 * len(w)                                   # the constant, kept where lin_offset sums it
+    return PottsModel(nodes, int(num_of_clusters), rowptr, col, val, c_pair=0.0, lin=lin,
+                      info={"kind": "cqm", "min_cluster_size": int(min_cluster_size)})
+
+
+def build_subsampling_qubo(G, gamma: float, P: float = 1.0) -> QuboModel:
+    """`graph_subsampling` -- QA_subsampling.py:28-35: ``Q[u,u] += -P (1 - w)``, ``Q[v,v] += -P (1 - w)``,
+    ``Q[u,v] += P (1 - w)`` per edge, ``Q[i,i] += gamma`` per node.  Sparse, no uniform pair term."""
+    nodes, eu, ev, w = graph_arrays(G)
+    n = len(nodes)
+    lin = np.full(n, float(gamma), dtype=np.float64)
+    np.add.at(lin, eu, -P * (1.0 - w))
+    np.add.at(lin, ev, -P * (1.0 - w))
+    rowptr, col, val = _csr_from_edges(n, eu, ev, P * (1.0 - w))
+    return QuboModel(nodes, lin, rowptr, col, val, c_pair=0.0, offset=0.0, info={"kind": "subsampling", "gamma": gamma})
+
+
+def build_mis_qubo(G, lagrange: float = 2.0) -> QuboModel:
+    """The QUBO ``dwave_networkx.maximum_independent_set`` hands to its sampler (QA_subsampling.py:102 calls
+    it; dwave_networkx is an absent third-party package, its published formulation is restated): ``-1`` on
+    every node, ``+lagrange`` on every edge."""
+    nodes, eu, ev, w = graph_arrays(G)
+    n = len(nodes)
+    rowptr, col, val = _csr_from_edges(n, eu, ev, np.full(len(w), float(lagrange)))
+    return QuboModel(nodes, np.full(n, -1.0), rowptr, col, val, c_pair=0.0, offset=0.0,
+                     info={"kind": "mis", "lagrange": lagrange})
+
+
 # --------------------------------------------------------------------------------------------
 # generic Q dict -> arrays (any caller of sample_qubo: QA_subsampling.py:28-35, other_tools.py:62 ...)
 # --------------------------------------------------------------------------------------------

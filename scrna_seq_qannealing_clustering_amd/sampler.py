@@ -56,7 +56,7 @@ class MI355XSampler:
     parameters = {
         "num_reads": [], "num_sweeps": [], "beta_range": [], "beta_schedule_type": [],
         "beta_schedule": [], "num_sweeps_per_beta": [], "seed": [], "initial_states": [],
-        "initial_states_generator": [], "resync_interval": [], "kernel": [],
+        "initial_states_generator": [], "resync_interval": [], "kernel": [], "min_cluster_size": [],
         **{k: [] for k in _IGNORED_KWARGS},
     }
     properties = {"category": "software", "beta_schedule_options": ("linear", "geometric", "custom"),
@@ -281,14 +281,21 @@ class MI355XSampler:
         prob = Problem.potts_csr(model.rowptr, model.col, model.val.astype(np.float32),
                                  float(np.float32(model.c_pair)), n, model.num_cases,
                                  lin_offset=model.lin_offset, device=self.device)
+        # the CQM's "every cluster has at least m members" (CQM_clustering.py:46-48): a hard constraint on moves
+        min_size = int(kw.get("min_cluster_size", model.info.get("min_cluster_size", 0)) or 0)
+        if min_size * model.num_cases > n:
+            raise ValueError("min_cluster_size %d x %d clusters exceeds the %d variables" % (min_size, model.num_cases, n))
         with prob:
             init_arr = init
-            if isinstance(init, tuple):
-                have = init[1]
+            if isinstance(init, tuple) or (min_size > 0 and init is None):
+                have = init[1] if isinstance(init, tuple) else np.zeros((0, n), dtype=np.uint16)
                 prob.anneal(num_reads, betas[:0], seed, self.replica_offset)
                 rnd, _, _ = prob.fetch(energies=False)
                 rnd[: have.shape[0]] = have
                 init_arr = rnd
+            if min_size > 0:
+                init_arr = _make_feasible(np.array(init_arr, dtype=np.uint16, copy=True), model.num_cases, min_size)
+                prob.set_option("min_cluster_size", min_size)
             t1 = time.perf_counter()
             prob.anneal(num_reads, betas, seed, self.replica_offset, init_arr)
             labels, dev_energy, stats = prob.fetch()
@@ -306,6 +313,21 @@ class MI355XSampler:
             "ignored_kwargs": ignored,
         }
         return SampleSet(labels.astype(np.int32), energies, model.variables, "DISCRETE", info=info)
+
+
+def _make_feasible(labels: np.ndarray, K: int, min_size: int) -> np.ndarray:
+    """Deterministic repair of initial labelings that leave a cluster below ``min_size``: members of the
+    largest clusters (highest indices first) are moved into the deficient ones."""
+    for r in range(labels.shape[0]):
+        cnt = np.bincount(labels[r], minlength=K)
+        for c in np.where(cnt < min_size)[0]:
+            while cnt[c] < min_size:
+                big = int(np.argmax(cnt))
+                i = int(np.where(labels[r] == big)[0][-1])
+                labels[r, i] = c
+                cnt[big] -= 1
+                cnt[c] += 1
+    return labels
 
 
 def _symmetric_f32(Qs64: np.ndarray) -> np.ndarray:
