@@ -63,7 +63,12 @@ def _knn_exact(X: np.ndarray, k: int, block: int = 2048) -> np.ndarray:
 
 
 def snn_from_points(X: np.ndarray, k: int, ord: Optional[int]) -> np.ndarray:
-    """Dense symmetric SNN weight matrix (zero diagonal), trimmed to degree <= ``ord`` if given."""
+    """Dense symmetric SNN weight matrix (zero diagonal), trimmed to degree <= ``ord`` if given.
+
+    A LITERAL dense numpy restatement of the R lines (O(n^2) memory, Python loop over columns): it generates
+    the small synthetic workloads of bench.py / the tests and pins oracle/snn_oracle.c.  It is not a fallback
+    of the product path: graphs are BUILT by ``snn.build_snn`` (GPU, csrc/snn_kernels.hip), which raises when
+    the HIP library is missing."""
     n = X.shape[0]
     nn = _knn_exact(X, k)
     M = np.zeros((n, n), dtype=np.float32)
