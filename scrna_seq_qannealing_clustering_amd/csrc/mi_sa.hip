@@ -93,6 +93,8 @@ struct mi_sa_problem {
     float *d_Qp = nullptr;
     float *d_Qm = nullptr;       // K1m: plain row-major Q2 + diagonal row (NT <= 44)
     float *d_Qs = nullptr;       // plain row-major copy (energy kernel), allocated lazily
+    float *d_Q2xl = nullptr, *d_diagxl = nullptr;   // K1x (n > 4096): padded rows of 2*Qs, diagonal
+    int xl_chunks = 0;
     // structured kinds (slot-ELL)
     int slots = 0, D = 0;
     float c_pair = 0.0f;
@@ -193,7 +195,8 @@ int dispatch_dense(mi_sa_problem *p, const DenseArgs &a, hipStream_t st)
     return fail(MI_EUNSUPPORTED, "dense kernel not built for NT=%d", p->NT);
 }
 
-constexpr int kMaxDenseN = 64 * 64;
+constexpr int kMaxDenseN = 64 * 64;        // register-per-wave kernels (K1, K1w, K1m)
+constexpr int kMaxDenseXlN = 16 * 4096;    // workgroup-per-replica kernel (K1x)
 
 }  // namespace
 
@@ -243,8 +246,8 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
 {
     if (!Qs || !out) return fail(MI_EINVAL, "NULL argument");
     if (n < 1) return fail(MI_EINVAL, "n must be >= 1 (got %d)", n);
-    if (n > kMaxDenseN)
-        return fail(MI_EUNSUPPORTED, "dense register-resident kernel supports n <= %d (got %d)", kMaxDenseN, n);
+    if (n > kMaxDenseXlN)
+        return fail(MI_EUNSUPPORTED, "dense kernels support n <= %d (got %d)", kMaxDenseXlN, n);
     int rc = select_device(device);
     if (rc) return rc;
     mi_sa_problem *p = new (std::nothrow) mi_sa_problem();
@@ -252,6 +255,34 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
     p->kind = MI_KIND_DENSE; p->n = n; p->offset = offset; p->state_elem = 1;
     rc = problem_common_init(p, device);
     if (rc) { mi_sa_problem_destroy(p); return rc; }
+    if (n > kMaxDenseN) {
+        // K1x: Q stays in HBM as n padded rows of 2*Qs (zero diagonal), uploaded in blocks of rows
+        p->xl_chunks = (n + 4095) / 4096;
+        const size_t xstride = (size_t)p->xl_chunks * 4096;
+        rc = [&]() -> int {
+            HIP_TRY(hipMalloc((void **)&p->d_Q2xl, (size_t)n * xstride * sizeof(float)));
+            HIP_TRY(hipMalloc((void **)&p->d_diagxl, xstride * sizeof(float)));
+            const int rows_per_block = 256;
+            std::vector<float> blk((size_t)rows_per_block * xstride), hd(xstride, 0.0f);
+            for (int r0 = 0; r0 < n; r0 += rows_per_block) {
+                const int nr = n - r0 < rows_per_block ? n - r0 : rows_per_block;
+                std::fill(blk.begin(), blk.begin() + (size_t)nr * xstride, 0.0f);
+                for (int i = 0; i < nr; ++i) {
+                    const float *row = Qs + (size_t)(r0 + i) * n;
+                    float *dst = blk.data() + (size_t)i * xstride;
+                    for (int j = 0; j < n; ++j) dst[j] = row[j] + row[j];
+                    dst[r0 + i] = 0.0f;
+                    hd[r0 + i] = row[r0 + i];
+                }
+                HIP_TRY(hipMemcpy(p->d_Q2xl + (size_t)r0 * xstride, blk.data(), (size_t)nr * xstride * sizeof(float), hipMemcpyHostToDevice));
+            }
+            HIP_TRY(hipMemcpy(p->d_diagxl, hd.data(), xstride * sizeof(float), hipMemcpyHostToDevice));
+            return MI_OK;
+        }();
+        if (rc) { mi_sa_problem_destroy(p); return rc; }
+        *out = p;
+        return MI_OK;
+    }
     const int slots = (n + 63) / 64;
     p->NT = ((slots + 3) / 4) * 4;
     const size_t stride = (size_t)p->NT * 64;
@@ -425,7 +456,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -514,7 +545,20 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
     HIP_TRY(hipMemsetAsync(p->d_stats, 0, 16 * sizeof(unsigned long long), p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));   // inputs resident before the timed region
 
-    if (p->kind == MI_KIND_DENSE) {
+    if (p->kind == MI_KIND_DENSE && p->xl_chunks > 0) {
+        DenseXlArgs a;
+        a.Q2 = p->d_Q2xl; a.diag = p->d_diagxl; a.temps = p->d_temps;
+        a.init = cont ? (const uint8_t *)p->d_states : (init ? (const uint8_t *)p->d_init : nullptr);
+        a.states = (uint8_t *)p->d_states; a.energy = p->d_energy; a.stats = p->d_stats;
+        a.offset = p->offset; a.n = p->n; a.R = R; a.num_sweeps = num_sweeps; a.resync = resync_interval;
+        a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+        a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
+        p->last_launches = 1;
+        HIP_TRY(hipEventRecord(p->ev0, p->stream));
+        rc = mi_launch_dense_xl(a, p->xl_chunks, p->stream);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    } else if (p->kind == MI_KIND_DENSE) {
         DenseArgs a;
         a.Qp = p->d_Qp; a.Qm = p->d_Qm; a.temps = p->d_temps;
         a.init = cont ? (const uint8_t *)p->d_states : (init ? (const uint8_t *)p->d_init : nullptr);

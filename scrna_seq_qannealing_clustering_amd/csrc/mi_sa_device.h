@@ -234,6 +234,32 @@ struct EllArgs {
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_potts(const EllArgs &, hipStream_t);
 
+// K1x (dense_xl_kernels.hip): dense chain for 4096 < n <= 65536, one workgroup per replica
+struct DenseXlArgs {
+    const float *Q2;        // n rows x (chunks*4096) floats: 2*Qs off-diagonal, 0 on the diagonal and in the padding
+    const float *diag;      // chunks*4096 floats (zero padded)
+    const float *temps;
+    const uint8_t *init;    // nullable, R x n
+    uint8_t *states;        // R x n
+    double *energy;         // R
+    unsigned long long *stats;
+    double offset;
+    int n, R, num_sweeps, resync;
+    uint32_t replica_offset, seed_lo, seed_hi, sweep_offset;
+    int temps_per_replica;
+};
+int mi_launch_dense_xl(const DenseXlArgs &, int chunks, hipStream_t);
+
+// random word of (variable i, sweep s, global replica g, tag) -- the per-variable form of the chain's RNG
+// addressing (one Philox block per call; the wave kernels share a block between four slots instead)
+__device__ __forceinline__ uint32_t chain_word_dev(uint32_t i, uint32_t s, uint32_t g, uint32_t tag, uint32_t k0, uint32_t k1)
+{
+    uint32_t w[4];
+    philox4x32_10(((i >> 8) << 6) | (i & 63u), s, g, tag, k0, k1, w);
+    const uint32_t sel = (i >> 6) & 3u;
+    return sel == 0 ? w[0] : (sel == 1 ? w[1] : (sel == 2 ? w[2] : w[3]));
+}
+
 // K4 launcher (energy_kernels.hip); all pointers are device pointers
 int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, double offset, double *dE,
                            uint8_t *dXt, int path, hipStream_t st);

@@ -238,7 +238,10 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         Problem.dense(np.array([[0.0, 1.0], [2.0, 0.0]], dtype=np.float32))       # not symmetric
     with pytest.raises(_lib.MiSaError) as ei:
-        Problem.dense(np.zeros((4097, 4097), dtype=np.float32))
+        # the size check precedes every access to the matrix: a tiny buffer is enough to ask for n = 65537
+        tiny = np.zeros(4, dtype=np.float32)
+        _lib.check(lib.mi_sa_problem_create_dense_f32(tiny.ctypes.data_as(C.POINTER(C.c_float)), 65537, 0.0, 0,
+                                                      C.byref(C.c_void_p())))
     assert ei.value.code == -5
     with pytest.raises(_lib.MiSaError):
         Problem.dense(np.zeros((4, 4), dtype=np.float32), device=99)
@@ -284,3 +287,31 @@ def test_full_size_properties_pbmc3k_surrogate():
     assert 0.05 < info["accepted"] / info["proposals"] < 0.7
     o2, oe2, os2 = so.sa_dense_philox(Qs, 2, betas[:8], 5, replica_offset=100)
     assert np.array_equal(s2, o2) and i2["accepted"] == int(os2[1])
+
+
+@pytest.mark.parametrize("n,R,sweeps", [(4097, 3, 3), (9000, 2, 2), (17000, 2, 2)])
+def test_dense_beyond_4096_variables_workgroup_per_replica(n, R, sweeps):
+    """K1x (one 512-thread workgroup per replica, fields spread over its registers, Q rows streamed from HBM)
+    is the same chain as K1: identical states and flip counts to the oracle at n = 4097 (2 chunks, ragged),
+    9000 (3 chunks) and 17000 (5 chunks), with initial states, a re-synchronisation and a replica offset.
+    Energies come from the cached fp32 fields here (1e-5 relative)."""
+    rng = np.random.RandomState(n)
+    Qs = np.zeros((n, n), dtype=np.float32)                      # ~2 % of the pairs coupled, symmetric
+    iu, ju = rng.randint(0, n, size=n * n // 100), rng.randint(0, n, size=n * n // 100)
+    vals = (rng.rand(len(iu)).astype(np.float32) - 0.5)
+    Qs[iu, ju] = vals
+    Qs = np.triu(Qs, 1)
+    Qs = np.ascontiguousarray(Qs + Qs.T)
+    Qs[np.arange(n), np.arange(n)] = rng.randn(n).astype(np.float32)
+    assert np.array_equal(Qs, Qs.T)
+    betas = np.geomspace(0.3, 3.0, sweeps)
+    init = rng.randint(0, 2, size=(R, n)).astype(np.uint8)
+    for kw in (dict(), dict(init=init, resync_interval=2)):
+        ost, oen, ostats = so.sa_dense_philox(Qs, R, betas, 11, replica_offset=5, **kw)
+        with Problem.dense(Qs) as p:
+            p.anneal(R, betas, 11, replica_offset=5, initial_states=kw.get("init"),
+                     resync_interval=kw.get("resync_interval", 0))
+            st, en, info = p.fetch()
+        assert info["accepted"] == int(ostats[1]) and info["accepted"] > n // 10
+        assert np.array_equal(st, ost)
+        assert np.allclose(en, oen, rtol=1e-5, atol=1e-3)
