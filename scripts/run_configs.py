@@ -50,7 +50,8 @@ X, truth = cloud(2638, 15, 9, 0)
 g = snn.build_snn(X, 5, 0.0, 15)
 pm = models.build_dqm_potts(g.to_graph(), 8, 0.005)
 S = 100 if a.quick else 1000
-with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(f32), float(f32(pm.c_pair)), 2638, 8, lin_offset=pm.lin_offset) as p:
+with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(f32), float(f32(pm.c_pair)), 2638, 8, lin_offset=pm.lin_offset,
+                       order="slots") as p:
     p.anneal(4096, models.make_beta_schedule(S, default_potts_beta_range(pm)), 1234)
     ms = p.kernel_ms()
     lab, en, info = p.fetch()
@@ -68,7 +69,7 @@ g = snn.build_snn(X, 5, 0.0, 15)
 t_build = time.perf_counter() - t0
 m = models.build_bqm_qubo(g.to_graph(), 0.05)
 S = 20 if a.quick else 200
-with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(f32), m.lin.astype(f32), float(f32(m.c_pair))) as p:
+with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(f32), m.lin.astype(f32), float(f32(m.c_pair)), order="slots") as p:
     p.anneal(1024, models.make_beta_schedule(S, models.default_beta_range(m)), 1234)
     ms = p.kernel_ms()
     st, en, info = p.fetch()
@@ -91,7 +92,8 @@ rungs, chains, rounds, sweeps_per_round = 8, 128, (4 if a.quick else 40), 10
 lo, hi = default_potts_beta_range(pm)
 ladder = np.geomspace(lo * 20, hi / 20, rungs)
 t0 = time.perf_counter()
-prob = Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(f32), float(f32(pm.c_pair)), n5, 15, lin_offset=pm.lin_offset)
+prob = Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(f32), float(f32(pm.c_pair)), n5, 15, lin_offset=pm.lin_offset,
+                         order="slots")
 kernel_ms = [0.0]
 
 

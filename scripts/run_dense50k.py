@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=50000)
 ap.add_argument("--replicas", type=int, default=256)
 ap.add_argument("--sweeps", type=int, default=2)
+ap.add_argument("--start", type=int, default=450, help="first beta of the 1000-step schedule to use")
 a = ap.parse_args()
 n = a.n
 rng = np.random.RandomState(1)
@@ -33,7 +34,7 @@ rows = np.repeat(np.arange(n), np.diff(m.rowptr))
 Qs[rows, m.col] += (m.val / 2.0).astype(np.float32)
 Qs[np.arange(n), np.arange(n)] = m.lin.astype(np.float32)
 t_build = time.perf_counter() - t0
-betas = models.make_beta_schedule(1000, models.default_beta_range(m))[200:200 + a.sweeps]   # mid-schedule temperatures
+betas = models.make_beta_schedule(1000, models.default_beta_range(m))[a.start:a.start + a.sweeps]   # temperatures from the middle of the schedule
 t0 = time.perf_counter()
 with Problem.dense(Qs) as p:
     t_upload = time.perf_counter() - t0

@@ -69,7 +69,15 @@ class Problem:
 
     @classmethod
     def potts_csr(cls, rowptr, col, val, c_pair: float, n: int, num_cases: int,
-                  lin_offset: float = 0.0, device: int = 0) -> "Problem":
+                  lin_offset: float = 0.0, device: int = 0, order: Optional[str] = None) -> "Problem":
+        """``order="slots"``: as in :meth:`csr_rank1` (labels go in and come out in the caller's order)."""
+        perm = None
+        if order == "slots":
+            from .models import permute_csr, slot_independent_order
+            perm = slot_independent_order(rowptr, col)
+            rowptr, col, val = permute_csr(rowptr, col, val, perm)
+        elif order is not None:
+            raise ValueError("order must be None or 'slots'")
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         col = np.ascontiguousarray(col, dtype=np.int32)
         val = np.ascontiguousarray(val, dtype=np.float32)
@@ -78,7 +86,7 @@ class Problem:
         _lib.check(lib.mi_sa_problem_create_potts_csr_f32(
             _ptr(rowptr, C.c_int32), _ptr(col, C.c_int32), _ptr(val, C.c_float), float(c_pair),
             int(n), int(num_cases), float(lin_offset), int(device), C.byref(h)))
-        return cls(h, _lib.KIND_POTTS_CSR, int(n), int(num_cases), device)
+        return cls(h, _lib.KIND_POTTS_CSR, int(n), int(num_cases), device, perm=perm)
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):

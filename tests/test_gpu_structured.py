@@ -162,6 +162,25 @@ def test_csr_rank1_slot_independent_order_and_integer_fast_path():
         assert np.array_equal(s_best, st[idx])
 
 
+def test_potts_slot_independent_order():
+    """K3 under order="slots": equal to the oracle on the renumbered model, labels returned in the caller's order."""
+    from scrna_seq_qannealing_clustering_amd.sampler import default_potts_beta_range
+    fx = load_fixture("varied")
+    pm = models.build_dqm_potts(fx.graph(), 5, 0.005)
+    perm = models.slot_independent_order(pm.rowptr, pm.col)
+    rp, cc, vv = models.permute_csr(pm.rowptr, pm.col, pm.val, perm)
+    betas = models.make_beta_schedule(30, default_potts_beta_range(pm))
+    init = np.random.RandomState(3).randint(0, 5, size=(6, 256)).astype(np.uint16)
+    olab, oen, ostats = so.potts_csr_philox(rp, cc, f32(vv), float(np.float32(pm.c_pair)), 256, 5, 6, betas, 9,
+                                            lin_offset=pm.lin_offset, init=np.ascontiguousarray(init[:, perm]))
+    with Problem.potts_csr(pm.rowptr, pm.col, f32(pm.val), float(np.float32(pm.c_pair)), 256, 5,
+                           lin_offset=pm.lin_offset, order="slots") as p:
+        p.anneal(6, betas, 9, initial_states=init)
+        lab, en, info = p.fetch()
+    assert np.array_equal(lab[:, perm], olab) and info["accepted"] == int(ostats[1])
+    assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+
+
 def test_csr_rank1_hot_schedule_and_launch_shapes():
     """Many flips per slot (a schedule that starts at ~100 % acceptance) and in-slot neighbour updates, for
     every workgroup shape: the chain does not depend on how replicas are packed into workgroups."""
