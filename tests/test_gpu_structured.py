@@ -237,10 +237,15 @@ def test_sample_dqm_like_clustering_dqm(kat):
     # P3: the same best energy as the CPU oracle's chain at equal (reads, sweeps, schedule, seed), and far
     # below a random labelling (the known labels-=-components value is kat["dqm_circles"]; single-site
     # Potts moves at 500 sweeps do not always merge the domains, on the oracle either)
+    # (the sampler sweeps in its slot-independent order: the oracle runs on the same renumbered model)
     betas = models.make_beta_schedule(500, ss.info["beta_range"])
-    olab, oen, _ = so.potts_csr_philox(pm.rowptr, pm.col, f32(pm.val), float(np.float32(pm.c_pair)), 256, 3,
+    perm = models.slot_independent_order(pm.rowptr, pm.col)
+    rp, cc, vv = models.permute_csr(pm.rowptr, pm.col, pm.val, perm)
+    olab, oen, _ = so.potts_csr_philox(rp, cc, f32(vv), float(np.float32(pm.c_pair)), 256, 3,
                                        64, betas, 5, lin_offset=pm.lin_offset)
-    assert pm.energies(olab).min() == pytest.approx(ss.first.energy, rel=1e-12)
+    unperm = np.empty_like(olab)
+    unperm[:, perm] = olab
+    assert pm.energies(unperm).min() == pytest.approx(ss.first.energy, rel=1e-12)
     rnd = np.random.RandomState(0).randint(0, 3, size=(16, 256))
     assert ss.first.energy < pm.energies(rnd).min() - 100.0
     assert ss.first.energy < kat["dqm_circles"]["E_pairwise"] + 60.0
