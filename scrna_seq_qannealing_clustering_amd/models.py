@@ -340,7 +340,7 @@ def slot_independent_order(rowptr: np.ndarray, col: np.ndarray, slot: int = 64) 
     col = np.asarray(col)
     n = len(rowptr) - 1
     nslots = (n + slot - 1) // slot
-    if nslots <= 1:
+    if nslots <= 1 or n > (1 << 18):                         # the greedy pass is O(n * slots): identity beyond 262144
         return np.arange(n, dtype=np.int64)
     cap = np.full(nslots, slot, dtype=np.int64)
     cap[-1] = n - slot * (nslots - 1)
