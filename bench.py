@@ -114,7 +114,7 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
         name, kname = "dense_bqm", "k_anneal_dense_wg<44,4>"
     else:
         p = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                              float(np.float32(m.c_pair)), device=rank_device)
+                              float(np.float32(m.c_pair)), device=rank_device, order="slots")
         name, kname = "csr_rank1_bqm", "k_anneal_csr_rank1<16>"
     with p:
         p.anneal(R, b, SEED)
@@ -126,7 +126,7 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
                      "acceptance": info["accepted"] / info["proposals"]}
     pm = models.build_dqm_potts(graph, 8, 0.005)
     with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(np.float32), float(np.float32(pm.c_pair)), n, 8,
-                           lin_offset=pm.lin_offset, device=rank_device) as p:
+                           lin_offset=pm.lin_offset, device=rank_device, order="slots") as p:
         b = models.make_beta_schedule(S, default_potts_beta_range(pm))
         p.anneal(R, b, SEED)
         ms = p.kernel_ms()
