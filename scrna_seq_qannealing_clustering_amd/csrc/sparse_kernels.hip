@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint32_t pk = cur.col[g0 + k / 4][k & 3];
-                const int msk = -(int)((word[k] >> (pk & 31u)) & 1u);
+                const int msk = __builtin_amdgcn_sbfe((int)word[k], pk, 1u);   // v_bfe_i32: bit pk[4:0] -> 0 / -1
                 gi = gi + __uint_as_float(cur.val[g0 + k / 4][k & 3] & (uint32_t)msk);
             }
         }
