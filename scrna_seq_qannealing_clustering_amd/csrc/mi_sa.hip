@@ -104,6 +104,7 @@ struct mi_sa_problem {
     uint32_t *d_meta = nullptr;              // K2: in-slot count | degree << 8
     uint4 *d_adj4 = nullptr;                 // K2: packed slot adjacency (see EllArgs::adj4)
     uint32_t *d_slot_flags = nullptr;        // K2: slots with internal edges
+    int k2_state_bytes = 0;                  // K2: byte-per-variable state (16 replicas x n bytes fit one CU's LDS)
     int cus = 0;
     // run buffers
     int cap_R = 0, cap_sweeps = 0;
@@ -383,6 +384,7 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
             // K2's register image of a slot: groups of four (neighbour, value) per lane, the neighbour already
             // translated into where its state bit lives in LDS (the state masks start at LDS address 0)
             const int G = D / 4;
+            p->k2_state_bytes = ((size_t)slots * 64 * 16 <= 144 * 1024) ? 1 : 0;     // n <= 9216
             std::vector<uint32_t> ha((size_t)slots * G * 2 * 64 * 4, 0u), hf((size_t)slots, 0u);
             for (int t = 0; t < slots; ++t)
                 for (int lane = 0; lane < 64; ++lane) {
@@ -392,7 +394,7 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
                         uint32_t vb;
                         memcpy(&vb, &hv[((size_t)t * D + k) * 64 + lane], 4);
                         const size_t base = (((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3);
-                        ha[base] = (((c >> 5) * 4u) << 8) | (c & 31u);
+                        ha[base] = p->k2_state_bytes ? c : ((((c >> 5) * 4u) << 8) | (c & 31u));
                         ha[base + 256] = vb;
                     }
                 }
@@ -578,7 +580,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         a.resync = resync_interval; a.slots = p->slots; a.D = p->D;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
-        a.rows = p->d_rows; a.meta = p->d_meta; a.adj4 = p->d_adj4; a.slot_flags = p->d_slot_flags; a.waves_override = p->opt_k2_waves; a.min_size = p->opt_min_cluster_size;
+        a.rows = p->d_rows; a.meta = p->d_meta; a.adj4 = p->d_adj4; a.slot_flags = p->d_slot_flags; a.state_bytes = p->k2_state_bytes; a.waves_override = p->opt_k2_waves; a.min_size = p->opt_min_cluster_size;
         if (p->kind == MI_KIND_POTTS_CSR && init) {
             // labels must be < K: validated on the host copy (the device trusts them as cnt[] indices)
             const uint16_t *l = static_cast<const uint16_t *>(init);

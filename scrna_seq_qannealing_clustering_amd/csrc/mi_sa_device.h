@@ -227,6 +227,7 @@ struct EllArgs {
     const uint32_t *meta;      // per variable: in-slot neighbour count | degree << 8
     const uint4 *adj4;         // K2: per slot, per group of 4 entries: [64][4] packed neighbours (LDS byte offset of
                                // the neighbour's 32-bit state word << 8 | bit), then [64][4] values
+    int state_bytes;           // K2: adj4 holds plain neighbour indices and the state is one byte per variable in LDS
     const uint32_t *slot_flags;// K2: per slot, non-zero when some variable of the slot has an in-slot neighbour
     int waves_override;        // (unused)
     int min_size;              // K3: a move out of a cluster with exactly min_size members is rejected (0 = off)

@@ -54,7 +54,10 @@ __device__ __forceinline__ void slot_words(uint32_t (&w)[4], int tg, int lane, u
 #define K2_TICK(var) do { } while (0)
 #endif
 
-template <int D>
+// XB: the state lives in LDS as one BYTE per variable (small models: 16 replicas x n bytes fit a CU) instead of
+// one bit: a neighbour's state is then a ds_read_u8 at its index and enters the field sum as fma(val, x, g) --
+// two VALU instructions per neighbour instead of four (address shift, bit extract, mask, add).
+template <int D, bool XB>
 __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllArgs a)
 {
     // ONE wavefront per workgroup: the replica's state masks start at LDS address 0, so the host can store
@@ -74,7 +77,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         for (int t = 0; t < slots; ++t) {
             const int i = t * 64 + lane;
             const uint64_t m = __ballot(i < n && init[(size_t)r * n + i]);
-            if (lane == 0) xm[t] = m;
+            if constexpr (XB) lds[i] = (char)((m >> lane) & 1ull);
+            else if (lane == 0) xm[t] = m;
             S += __popcll(m);
         }
     } else {
@@ -86,7 +90,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
                 const int t = 4 * tg + c;
                 if (t >= slots) break;
                 const uint64_t m = __ballot(t * 64 + lane < n && (w[c] >> 31));
-                if (lane == 0) xm[t] = m;
+                if constexpr (XB) lds[t * 64 + lane] = (char)((m >> lane) & 1ull);
+                else if (lane == 0) xm[t] = m;
                 S += __popcll(m);
             }
         }
@@ -149,22 +154,35 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         for (int g0 = 0; g0 < G; g0 += 4) {                   // 16 state words in flight, then 16 adds
             uint32_t word[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                word[k] = *reinterpret_cast<const uint32_t *>(lds + (cur.col[g0 + k / 4][k & 3] >> 8));
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t pk = cur.col[g0 + k / 4][k & 3];
+                if constexpr (XB) word[k] = (uint32_t)(unsigned char)lds[pk];           // packed word = the index
+                else word[k] = *reinterpret_cast<const uint32_t *>(lds + (pk >> 8));
+            }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint32_t pk = cur.col[g0 + k / 4][k & 3];
-                const int msk = __builtin_amdgcn_sbfe((int)word[k], pk, 1u);   // v_bfe_i32: bit pk[4:0] -> 0 / -1
-                gi = gi + __uint_as_float(cur.val[g0 + k / 4][k & 3] & (uint32_t)msk);
+                if constexpr (XB) {
+                    // fma(val, 1, g) = g + val and fma(val, 0, g) = g: the oracle's conditional add, one rounding
+                    gi = __fmaf_rn(__uint_as_float(cur.val[g0 + k / 4][k & 3]), (float)word[k], gi);
+                } else {
+                    const int msk = __builtin_amdgcn_sbfe((int)word[k], pk, 1u);   // v_bfe_i32: bit pk[4:0] -> 0 / -1
+                    gi = gi + __uint_as_float(cur.val[g0 + k / 4][k & 3] & (uint32_t)msk);
+                }
             }
         }
         K2_TICK(t_apply);
         float thr = neglog_u(wc) * T;
         if (i >= n) thr = -INFINITY;
-        const uint64_t xm_v = xm[t];                          // same word in every lane: make it scalar
-        const uint64_t xm_t = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xm_v >> 32)) << 32) |
-                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xm_v);
+        uint64_t xm_t;                                        // the slot's 64 state bits as a scalar
+        if constexpr (XB) {
+            xm_t = __ballot(lds[i] != 0);
+        } else {
+            const uint64_t xm_v = xm[t];                      // same word in every lane: make it scalar
+            xm_t = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xm_v >> 32)) << 32) |
+                   (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xm_v);
+        }
         const uint32_t xi = (uint32_t)((xm_t >> lane) & 1ull);
         const uint32_t sgnbit = xi << 31;                     // dE = x ? -f : f
         uint64_t todo = ~0ull, flipped = 0ull;
@@ -276,7 +294,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         }
         if (flipped) {                                        // wave-uniform
             accepted += (unsigned long long)__popcll(flipped);
-            if (lane == 0) xm[t] = xm_t ^ flipped;
+            if constexpr (XB) { if ((flipped >> lane) & 1ull) lds[i] = (char)(xi ^ 1u); }
+            else if (lane == 0) xm[t] = xm_t ^ flipped;
         }
         K2_TICK(t_loop);
     };
@@ -315,7 +334,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
     double e = 0.0;
     for (int t = 0; t < slots; ++t) {
         const int i = t * 64 + lane;
-        const uint64_t m = xm[t];
+        const uint64_t m = XB ? __ballot(lds[i] != 0) : xm[t];
         const int on = (int)((m >> lane) & 1ull);
         if (i < n) dst[i] = (uint8_t)on;
         cnt += __popcll(m);
@@ -324,7 +343,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         for (int k = 0; k < D; ++k) {
             const uint32_t cc = a.ell_col[((size_t)t * D + k) * 64 + lane];
             const float vv = a.ell_val[((size_t)t * D + k) * 64 + lane];
-            if ((xm[cc >> 6] >> (cc & 63u)) & 1ull) acc += (double)vv;
+            const bool xc = XB ? (lds[cc] != 0) : (bool)((xm[cc >> 6] >> (cc & 63u)) & 1ull);
+            if (xc) acc += (double)vv;
         }
         e += (double)a.lin[i] + 0.5 * acc;
     }
@@ -511,11 +531,10 @@ int launch_sparse(KernelT kernel, const EllArgs &a, size_t lds_per_wave, hipStre
 }
 
 template <typename KernelT>
-int launch_csr_rank1(KernelT kernel, const EllArgs &a, hipStream_t st)
+int launch_csr_rank1(KernelT kernel, const EllArgs &a, size_t lds, hipStream_t st)
 {
-    // one wavefront = one replica = one workgroup; the only LDS is the state mask (8 bytes per slot)
-    const size_t lds = (size_t)a.slots * 8;
-    if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1: n = %d exceeds the state-mask LDS budget", a.n);
+    // one wavefront = one replica = one workgroup; the only LDS is the state (a bit or a byte per variable)
+    if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1: n = %d exceeds the state LDS budget", a.n);
     if (!a.adj4 || !a.slot_flags) return fail(MI_EHIP, "csr_rank1: packed adjacency missing");
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -528,9 +547,16 @@ int launch_csr_rank1(KernelT kernel, const EllArgs &a, hipStream_t st)
 
 int mi_launch_csr_rank1(const EllArgs &a, hipStream_t st)
 {
-    if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16>, a, st);
-    if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32>, a, st);
-    if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64>, a, st);
+    const size_t bits = (size_t)a.slots * 8, bytes = (size_t)a.slots * 64;
+    if (a.state_bytes) {
+        if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, true>, a, bytes, st);
+        if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, true>, a, bytes, st);
+        if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, true>, a, bytes, st);
+    } else {
+        if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, false>, a, bits, st);
+        if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, false>, a, bits, st);
+        if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, false>, a, bits, st);
+    }
     return fail(MI_EUNSUPPORTED, "slot-ELL width %d not built", a.D);
 }
 
