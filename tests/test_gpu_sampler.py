@@ -68,3 +68,24 @@ def test_initial_states_generators():
     assert len(ss) == 6                                            # 2 given + 4 random, all distinct
     with pytest.raises(ValueError):
         sampler.sample_qubo(m, initial_states=(init, fx.nodes), num_reads=6, initial_states_generator="none")
+
+
+def test_config1_on_the_gpu():
+    """BASELINE config 1 through the drop-in surface: the reference's Q DICT for the n = 512 surrogate graph
+    (BQM_clustering.py:36-47 builds exactly this) handed to MI355XSampler.sample_qubo with the reference's
+    keyword arguments; best energy no worse than the oracle's neal restatement at equal reads and sweeps."""
+    from oracle import model_oracle as mo
+    from oracle import sa_oracle as so
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(512, 5, 15, 15, 9, seed=0)
+    edges = [(nodes[a], nodes[b], float(c)) for a, b, c in zip(eu, ev, w)]
+    Q, gamma = mo.q_bqm(nodes, edges, 0.05, k=8)                   # the literal defaultdict, 131 328 entries
+    ss = MI355XSampler().sample_qubo(Q, label="config1", chain_strength=4, num_reads=64, num_sweeps=1000, seed=7)
+    assert ss.info["kernel"] == "csr_rank1"                        # the uniform 2*gamma pair term was split off
+    assert len(ss.first.sample) == 512 and set(ss.first.sample.values()) <= {0, 1}
+    assert ss.first.energy == pytest.approx(mo.qubo_energy(Q, dict(ss.first.sample)), rel=1e-9)
+    m = models.build_bqm_qubo(graphs.EdgeListGraph(nodes, eu, ev, w), 0.05, k=8)
+    betas = models.make_beta_schedule(1000, ss.info["beta_range"])
+    h, J, off = so.qubo_to_ising_dense(m.dense_Qs())
+    _, en_ising, _ = so.sa_ising_neal_dense(h, J, 64, betas, seed=7, threads=8)
+    assert ss.first.energy <= (en_ising + off).min() + 1e-6 * abs(ss.first.energy)
