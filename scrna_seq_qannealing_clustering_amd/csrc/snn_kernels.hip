@@ -15,11 +15,14 @@
 //                      LDS (one per point) by walking RN(m) for m in N(i); a second walk reads-and-clears
 //                      them (atomic AND: the first visitor of a duplicate candidate wins).  Pass 0 counts the
 //                      row, pass 1 emits it, bitonic-sorted by column.  Integer / LDS-atomic bound.
-//   S4 k_trim          ONE workgroup walks the columns in order (the reference's loop is sequential and in
-//                      place: what column i sees depends on what columns < i deleted).  Latency-bound by design.
+//   S4 k_trim_par      the reference's trim loop is sequential and in place (what column i sees depends on
+//                      what columns < i deleted); column i only depends on its smaller NEIGHBOURS, so many
+//                      columns are in flight, each waiting for those (k_trim = the one-workgroup fallback).
 //   S5 k_compact_*     drops the deleted entries.
 #include <climits>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/mi_snn.h"
@@ -260,6 +263,86 @@ __global__ void __launch_bounds__(kTrimThreads) k_trim(int n, int ord, const int
     }
 }
 
+// The same loop, many columns in flight.  Column i only depends on the columns j < i that are its neighbours
+// in the UNTRIMMED graph (step j deletes entries of row/column j only), so workgroups claim columns in index
+// order from a counter and each waits -- bounded by a clock AND an iteration cap -- until those neighbours are
+// done.  A column is claimed only by a running workgroup and only after every smaller column has been
+// claimed, so the smallest unfinished column never waits on anything unfinished: no deadlock.  A wait that
+// hits its bound raises ctrl[1] (the host then redoes the trim with the sequential kernel) and proceeds.
+//   ctrl[0] = next column to claim, ctrl[1] = error flag;  done[i] = 1 once column i has been processed.
+constexpr int kTrimParThreads = 64;
+constexpr long long kTrimWaitTicks = 500000;       // 5 ms of the 100 MHz realtime clock
+__global__ void __launch_bounds__(kTrimParThreads) k_trim_par(int n, int ord, const int *__restrict__ rowptr,
+                                                              const int32_t *__restrict__ col,
+                                                              const int32_t *__restrict__ shared, unsigned char *alive,
+                                                              unsigned int *ctrl, unsigned int *done)
+{
+    __shared__ int key[kRowCap];
+    __shared__ int nalive, claimed, waits_ok;
+    for (int iter = 0; iter <= n; ++iter) {                         // a workgroup can never claim more than n columns
+        if (threadIdx.x == 0) { claimed = (int)atomicAdd(&ctrl[0], 1u); nalive = 0; waits_ok = 1; }
+        __syncthreads();
+        const int i = claimed;
+        if (i >= n) return;                                         // uniform
+        const int base = rowptr[i], deg = rowptr[i + 1] - base;
+        if (deg > ord) {                                            // uniform: only such columns can delete
+            // wait for the smaller neighbours (one lane per entry; the column list is ascending)
+            for (int e = threadIdx.x; e < deg; e += kTrimParThreads) {
+                const int j = col[base + e];
+                if (j >= i) break;
+                const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                int spins = 0;
+                while (__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    if (++spins > 200000 || (long long)__builtin_amdgcn_s_memrealtime() - t0 > kTrimWaitTicks) {
+                        waits_ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __threadfence();                                        // acquire side: the flags were read relaxed
+            __syncthreads();
+            if (!waits_ok && threadIdx.x == 0) __hip_atomic_store(&ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int mine = 0;
+            for (int e = threadIdx.x; e < deg; e += kTrimParThreads) {
+                const unsigned char al = __hip_atomic_load(&alive[base + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                key[e] = al ? shared[base + e] : -1;
+                mine += al ? 1 : 0;
+            }
+            if (mine) atomicAdd(&nalive, mine);
+            __syncthreads();
+            if (nalive > ord) {                                     // uniform
+                for (int e = threadIdx.x; e < deg; e += kTrimParThreads) {
+                    const int ke = key[e];
+                    if (ke < 0) continue;
+                    int rank = 0;
+                    for (int f = 0; f < deg; ++f) {
+                        const int kf = key[f];
+                        rank += (kf > ke || (kf == ke && f < e)) ? 1 : 0;
+                    }
+                    if (rank >= ord) {
+                        __hip_atomic_store(&alive[base + e], (unsigned char)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int j = col[base + e];
+                        int lo = rowptr[j], hi = rowptr[j + 1] - 1;
+                        while (lo <= hi) {
+                            const int mid = (lo + hi) >> 1;
+                            const int cm = col[mid];
+                            if (cm == i) {
+                                __hip_atomic_store(&alive[mid], (unsigned char)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                            if (cm < i) lo = mid + 1; else hi = mid - 1;
+                        }
+                    }
+                }
+            }
+            __threadfence();                                        // release side: deletions before the flag
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&done[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_compact_count(int n, const int *__restrict__ rowptr,
                                                        const unsigned char *__restrict__ alive, int *__restrict__ deg,
                                                        int *__restrict__ maxdeg)
@@ -406,7 +489,30 @@ int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int or
         HIP_TRY(hipEventRecord(ev[2], st));
 
         // S4: the sequential symmetric trim, S5: compaction
-        if (ord > 0) hipLaunchKernelGGL(k_trim, dim3(1), dim3(kTrimThreads), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0, d_alive);
+        if (ord > 0 && !getenv("MI_SNN_TRIM_SEQUENTIAL")) {
+            // many columns in flight (k_trim_par); the sequential kernel is the fallback should a dependency
+            // wait ever hit its bound (MI_SNN_TRIM_SEQUENTIAL=1 forces it)
+            unsigned int *d_tctrl = nullptr, *d_done = nullptr;
+            HIP_TRY(hipMalloc((void **)&d_tctrl, 2 * sizeof(unsigned int)));
+            HIP_TRY(hipMalloc((void **)&d_done, (size_t)n * sizeof(unsigned int)));
+            HIP_TRY(hipMemsetAsync(d_tctrl, 0, 2 * sizeof(unsigned int), st));
+            HIP_TRY(hipMemsetAsync(d_done, 0, (size_t)n * sizeof(unsigned int), st));
+            const int tgrid = cus * 2;
+            hipLaunchKernelGGL(k_trim_par, dim3(tgrid), dim3(kTrimParThreads), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0,
+                               d_alive, d_tctrl, d_done);
+            unsigned int terr = 0;
+            HIP_TRY(hipMemcpyAsync(&terr, d_tctrl + 1, sizeof terr, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            (void)hipFree(d_tctrl);
+            (void)hipFree(d_done);
+            if (terr) {
+                fprintf(stderr, "mi_snn: parallel trim hit a wait bound; redoing sequentially\n");
+                HIP_TRY(hipMemsetAsync(d_alive, 1, (size_t)(nnz0 > 0 ? nnz0 : 1), st));
+                hipLaunchKernelGGL(k_trim, dim3(1), dim3(kTrimThreads), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0, d_alive);
+            }
+        } else if (ord > 0) {
+            hipLaunchKernelGGL(k_trim, dim3(1), dim3(kTrimThreads), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0, d_alive);
+        }
         HIP_TRY(hipMemsetAsync(d_err + 1, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_compact_count, dim3((n + 255) / 256), dim3(256), 0, st, n, (const int *)d_ptr0, d_alive, d_deg, d_err + 1);
         hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, d_deg, g->d_ptr, n);
