@@ -31,7 +31,7 @@
 namespace mi_sa_impl {
 namespace {
 
-constexpr int kKnnThreads = 256;
+constexpr int kKnnThreads = 64;       // one wavefront per workgroup: 782 workgroups at n = 50 000 (3 per CU)
 
 template <int DP, int KM>
 __global__ void __launch_bounds__(kKnnThreads) k_knn(const float *__restrict__ X, int n, int dim, int k,
@@ -57,27 +57,39 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn(const float *__restrict__ X
         }
         __syncthreads();
         const int lim = n - j0 < kKnnThreads ? n - j0 : kKnnThreads;
-        for (int jj = 0; jj < lim; ++jj) {
-            const f32x4 *tp = reinterpret_cast<const f32x4 *>(tile + jj * DP);
-            float d = 0.0f;
+        // four candidates at a time: four independent fmaf chains in flight (one chain is 16 dependent
+        // instructions), then the (rare) insertions in candidate order.  Rows past `lim` in the tile are
+        // zero-filled and masked out by j < n.
+        for (int jj = 0; jj < lim; jj += 4) {
+            float d4[4];
 #pragma unroll
-            for (int c4 = 0; c4 < DP / 4; ++c4) {
-                const f32x4 v = tp[c4];                   // same address in every lane: LDS broadcast
-                float df;
-                df = xq[4 * c4 + 0] - v.x; d = __fmaf_rn(df, df, d);
-                df = xq[4 * c4 + 1] - v.y; d = __fmaf_rn(df, df, d);
-                df = xq[4 * c4 + 2] - v.z; d = __fmaf_rn(df, df, d);
-                df = xq[4 * c4 + 3] - v.w; d = __fmaf_rn(df, df, d);
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 *tp = reinterpret_cast<const f32x4 *>(tile + (jj + u) * DP);
+                float d = 0.0f;
+#pragma unroll
+                for (int c4 = 0; c4 < DP / 4; ++c4) {
+                    const f32x4 v = tp[c4];               // same address in every lane: LDS broadcast
+                    float df;
+                    df = xq[4 * c4 + 0] - v.x; d = __fmaf_rn(df, df, d);
+                    df = xq[4 * c4 + 1] - v.y; d = __fmaf_rn(df, df, d);
+                    df = xq[4 * c4 + 2] - v.z; d = __fmaf_rn(df, df, d);
+                    df = xq[4 * c4 + 3] - v.w; d = __fmaf_rn(df, df, d);
+                }
+                d4[u] = d;
             }
-            const int j = j0 + jj;
-            if (j != i && d < bd[KM - 1]) {               // candidates arrive by ascending j: equal d never displaces
-                bd[KM - 1] = d;
-                bj[KM - 1] = j;
 #pragma unroll
-                for (int p = KM - 1; p > 0; --p) {
-                    if (bd[p] < bd[p - 1]) {
-                        const float td = bd[p]; bd[p] = bd[p - 1]; bd[p - 1] = td;
-                        const int tj = bj[p]; bj[p] = bj[p - 1]; bj[p - 1] = tj;
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + jj + u;
+                const float d = d4[u];
+                if (j < n && j != i && d < bd[KM - 1]) {  // candidates arrive by ascending j: equal d never displaces
+                    bd[KM - 1] = d;
+                    bj[KM - 1] = j;
+#pragma unroll
+                    for (int p = KM - 1; p > 0; --p) {
+                        if (bd[p] < bd[p - 1]) {
+                            const float td = bd[p]; bd[p] = bd[p - 1]; bd[p - 1] = td;
+                            const int tj = bj[p]; bj[p] = bj[p - 1]; bj[p - 1] = tj;
+                        }
                     }
                 }
             }
