@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""K4 (batched energy on the f32-input MFMA) at the BASELINE config 2 shape: 4096 states x n = 2638.
+Run under rocprofv3 --pmc (scripts/pmc_k4.sh) for the MFMA counters; prints the kernel time and TFLOP/s."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from scrna_seq_qannealing_clustering_amd import engine  # noqa: E402
+
+m, Qs, betas, _, _ = bench.build_workload()
+X = np.random.RandomState(0).randint(0, 2, size=(4096, Qs.shape[0])).astype(np.uint8)
+for path in (2, 2, 1):
+    e, ms = engine.energy_dense(Qs, X, path=path, return_ms=True)
+    print("path %d: %.3f ms  %.1f TFLOP/s (2 n^2 R flop)" % (path, ms, 2.0 * Qs.shape[0] ** 2 * 4096 / ms / 1e9), flush=True)
+assert np.allclose(e, m.energies(X), rtol=1e-5)
