@@ -696,7 +696,7 @@ int mi_energy_dense_f32_ex(const float *Qs, int n, const uint8_t *X, int R, doub
     float *dQ = nullptr; uint8_t *dX = nullptr, *dXt = nullptr; double *dE = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     rc = [&]() -> int {
-        const size_t Rpad = ((size_t)R + 63) / 64 * 64;
+        const size_t Rpad = ((size_t)R + 127) / 128 * 128;
         HIP_TRY(hipMalloc((void **)&dQ, (size_t)n * n * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&dX, (size_t)R * n));
         HIP_TRY(hipMalloc((void **)&dE, (size_t)R * sizeof(double)));
