@@ -115,7 +115,7 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
     else:
         p = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
                               float(np.float32(m.c_pair)), device=rank_device, order="slots")
-        name, kname = "csr_rank1_bqm", "k_anneal_csr_rank1<16>"
+        name, kname = "csr_rank1_bqm", "k_anneal_csr_rank1<16, true>"
     with p:
         p.anneal(R, b, SEED)
         ms = p.kernel_ms()
@@ -179,7 +179,7 @@ def main():
     else:
         prob = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
                                  float(np.float32(m.c_pair)), device=local, order="slots")   # as the sampler does
-        kernel_name = "k_anneal_csr_rank1<16>"
+        kernel_name = "k_anneal_csr_rank1<16, true>"          # byte-state variant (n <= 9216)
         bytes_per_update = 8.0 * float(np.diff(m.rowptr).mean()) + 8.0      # deg_i*(4+4) + 8
         layout = "CSR (cut term) + uniform pair term, %.1f neighbours per cell on average" % float(np.diff(m.rowptr).mean())
 

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
 {
     __shared__ __attribute__((aligned(16))) float As[2][kGemmKC][kGemmTile];
     __shared__ __attribute__((aligned(16))) float Bs[2][kGemmKC][kGemmTile];
-    __shared__ unsigned char Xs[kGemmTile][kGemmTile];           // X[i][r] of this tile (the reduction mask)
+    __shared__ unsigned int Xs[kGemmTile][kGemmTile / 32];        // X[i][r] of this tile as bits (the reduction mask)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = (blockIdx.x % row_tiles) * kGemmTile;
     const int r0 = (blockIdx.x / row_tiles) * kGemmTile;
@@ -112,12 +112,19 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
             *reinterpret_cast<f32x4 *>(&Bs[b][kk][c4]) = bv;
         }
     };
-    // the mask tile: X[i0 + ii][r0 + rr]
-    for (int e = tid; e < kGemmTile * kGemmTile / 4; e += 256) {
-        const int ii = e >> 5, c4 = (e & 31) * 4;
-        unsigned int xw = 0u;
-        if (i0 + ii < n) xw = *reinterpret_cast<const unsigned int *>(Xt + (size_t)(i0 + ii) * Rpad + r0 + c4);
-        *reinterpret_cast<unsigned int *>(&Xs[ii][c4]) = xw;
+    // the mask tile: bit (rr & 31) of Xs[ii][rr >> 5] = X[i0 + ii][r0 + rr]
+    for (int e = tid; e < kGemmTile * (kGemmTile / 32); e += 256) {
+        const int ii = e >> 2, w = e & 3;
+        unsigned int bits = 0u;
+        if (i0 + ii < n) {
+            const uint8_t *src = Xt + (size_t)(i0 + ii) * Rpad + r0 + 32 * w;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned int xw = *reinterpret_cast<const unsigned int *>(src + 4 * q);
+                bits |= ((xw & 1u) | ((xw >> 7) & 2u) | ((xw >> 14) & 4u) | ((xw >> 21) & 8u)) << (4 * q);
+            }
+        }
+        Xs[ii][w] = bits;
     }
 
     f32x16 acc[2][2];
@@ -151,8 +158,8 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = wi + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * half;
-                m0[q] = Xs[row][wr + col] ? acc[a][0][q] : 0.0f;
-                m1[q] = Xs[row][wr + 32 + col] ? acc[a][1][q] : 0.0f;
+                m0[q] = ((Xs[row][wr >> 5] >> col) & 1u) ? acc[a][0][q] : 0.0f;
+                m1[q] = ((Xs[row][(wr >> 5) + 1] >> col) & 1u) ? acc[a][1][q] : 0.0f;
                 acc[a][0][q] = 0.0f;
                 acc[a][1][q] = 0.0f;
             }
