@@ -417,6 +417,11 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
 
     unsigned long long accepted = 0;
     const float min_sz = (float)a.min_size;
+    const bool use_min = a.min_size > 0;                     // wave-uniform
+    // w mod (K-1) for a 32-bit w without the 40-instruction integer division: q = mulhi(w, floor(2^32/d)) is
+    // floor(w/d) or one less, so the remainder needs at most one correction (d = K-1 <= 63)
+    const uint32_t dK = (uint32_t)(K > 1 ? K - 1 : 1);
+    const uint32_t magic = (uint32_t)(0x100000000ull / dK);
     for (int s = 0; s < a.num_sweeps && K > 1; ++s) {
         const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
             __float_as_int(a.temps[a.temps_per_replica ? r : s])));
@@ -443,7 +448,10 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             float thr = neglog_u(w0c) * T;
             if (i >= n) thr = -INFINITY;
             const int la = lab[i];
-            const int lb = (la + 1 + (int)(w2c % (uint32_t)(K - 1))) % K;
+            uint32_t rem = w2c - __umulhi(w2c, magic) * dK;  // in [0, 2 dK)
+            rem = rem >= dK ? rem - dK : rem;
+            int lb = la + 1 + (int)rem;                      // in [1, 2K - 2]
+            lb = lb >= K ? lb - K : lb;
             float ha = 0.0f, hb = 0.0f;
             auto sum_h = [&]() {
                 ha = 0.0f;
@@ -465,7 +473,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                 const float eb = hb + a.c_pair * fb;
                 const float dE = eb - ea;
                 // fa = (members of this lane's cluster) - 1: a move may not shrink a cluster below min_size
-                const uint64_t m = __ballot(dE < thr && fa >= min_sz) & todo;
+                const uint64_t m = (use_min ? __ballot(dE < thr && fa >= min_sz) : __ballot(dE < thr)) & todo;
                 if (m == 0) break;
                 const int l = __ffsll((unsigned long long)m) - 1;
                 todo = (~0ull << l) << 1;
