@@ -246,8 +246,21 @@ def clustering_cqm(G, num_of_clusters, min_cluster_size: int = 20, sampler=None,
     return sampleset
 
 
-def one_hot_sample(sample, num_of_clusters):
-    """label dict {node: k}  ->  the CQM's binary dict {'v_<node>,<k>': 0/1} (CQM_clustering.py:34)."""
+def clustering_cqm_2(G, num_of_clusters, min_cluster_size: int = 20, sampler=None,
+                     sampler_kwargs: Optional[dict] = None, verbose=False):
+    """`clustering_cqm_2` (CQM_clustering.py:57-90): the same model on a SUBGRAPH whose nodes carry a
+    ``"subindex"`` attribute (their position in the subgraph) -- the reference only uses it to name the
+    binaries ``v_<subindex>,<k>``.  Solved exactly like :func:`clustering_cqm`;
+    ``one_hot_sample(sample, K, G)`` names the binaries by subindex."""
+    return clustering_cqm(G, num_of_clusters, min_cluster_size, sampler, sampler_kwargs, verbose)
+
+
+def one_hot_sample(sample, num_of_clusters, G=None):
+    """label dict {node: k}  ->  the CQM's binary dict {'v_<node>,<k>': 0/1} (CQM_clustering.py:34); with ``G``
+    given, nodes are named by their ``"subindex"`` attribute (:65)."""
+    if G is not None:
+        return {"v_%s,%d" % (G.nodes[node]["subindex"], k): int(k == lab)
+                for node, lab in sample.items() for k in range(num_of_clusters)}
     return {"v_%s,%d" % (node, k): int(k == lab) for node, lab in sample.items() for k in range(num_of_clusters)}
 
 
