@@ -99,6 +99,19 @@ def pmc_traffic(replicas, sweeps, launches, kernel):
     return None
 
 
+def binding_resource(kernel):
+    """What actually binds the timed kernel, from the committed SQ-counter passes (profiles/r01_k2_binding.json,
+    scripts/pmc_k2.sh + scripts/k2_binding.py): the byte model of `roofline` is an effective-bandwidth figure
+    for a model that lives in L2."""
+    if not kernel.startswith("k_anneal_csr_rank1"):
+        return None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_k2_binding.json")))
+    except (OSError, ValueError):
+        return None
+    return {k: rec[k] for k in ("resource", "utilisation", "salu_issue_utilisation", "l2_hit_rate", "source")}
+
+
 def other_kernels(m, Qs, betas, graph, rank_device, headline):
     """Short untimed-region runs of the other kernels on the same graph (reported beside the headline, never
     part of `value`): the same QUBO on the other binary kernel, and K3 = BASELINE config 3 (DQM K=8)."""
@@ -247,6 +260,7 @@ def main():
                      "kernel_ms_per_step": k_ms,
                      "algorithmic_bytes_per_update": bytes_per_update,
                      "algorithmic_bytes_per_launch": alg_bytes,
+                     "binding_resource": binding_resource(kernel_name),
                      "rows_GBps": row_bytes / (k_ms * 1e-3) / 1e9,
                      "acceptance": info["accepted"] / info["proposals"]},
         "best_energy": float(m.energies(best_state[None, :])[0]),
