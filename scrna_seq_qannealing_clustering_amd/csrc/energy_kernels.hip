@@ -89,8 +89,12 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
     const int wi = (wave & 1) * 64, wr = (wave >> 1) * 64;       // this wave's 64 x 64 corner inside the tile
     const int half = lane >> 5, col = lane & 31;
 
-    // stage chunk c (k = 32 c .. 32 c + 31) into buffer b: 256 threads x (4 floats of A, 4 bytes of X)
-    auto stage = [&](int c, int b) {
+    // staging of chunk c (k = 32 c .. 32 c + 31) in two halves, so that the global loads of chunk c+1 are in
+    // flight WHILE the MFMAs of chunk c run: load_chunk issues them into registers, store_chunk (after the
+    // MFMAs) widens the state bytes and writes both operands to the other LDS buffer.
+    f32x4 st_a[4];
+    unsigned int st_x[4];
+    auto load_chunk = [&](int c) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + 256 * q;                         // 1024 float4 slots: [k][32 float4]
@@ -107,7 +111,17 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
                 }
                 xw = *reinterpret_cast<const unsigned int *>(Xt + (size_t)k * Rpad + r0 + c4);   // Rpad, r0: multiples of 128
             }
-            *reinterpret_cast<f32x4 *>(&As[b][kk][c4]) = av;
+            st_a[q] = av;
+            st_x[q] = xw;
+        }
+    };
+    auto store_chunk = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            const int kk = e >> 5, c4 = (e & 31) * 4;
+            const unsigned int xw = st_x[q];
+            *reinterpret_cast<f32x4 *>(&As[b][kk][c4]) = st_a[q];
             f32x4 bv = {(float)(xw & 0xffu), (float)((xw >> 8) & 0xffu), (float)((xw >> 16) & 0xffu), (float)(xw >> 24)};
             *reinterpret_cast<f32x4 *>(&Bs[b][kk][c4]) = bv;
         }
@@ -135,11 +149,12 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
     double e_lo = 0.0, e_hi = 0.0;                               // states wr + col and wr + 32 + col
 
     const int chunks = (n + kGemmKC - 1) / kGemmKC;
-    stage(0, 0);
+    load_chunk(0);
+    store_chunk(0);
     __syncthreads();
     for (int c = 0; c < chunks; ++c) {
         const int b = c & 1;
-        if (c + 1 < chunks) stage(c + 1, b ^ 1);                 // overlaps with the MFMAs below
+        if (c + 1 < chunks) load_chunk(c + 1);                   // global loads in flight during the MFMAs below
 #pragma unroll
         for (int k0 = 0; k0 < kGemmKC; k0 += 2) {
             const float a0 = As[b][k0 + half][wi + col], a1 = As[b][k0 + half][wi + 32 + col];
@@ -149,6 +164,7 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (c + 1 < chunks) store_chunk(b ^ 1);                  // (buffer b^1 was last read before the previous barrier)
         // fold the <= 32-term fp32 partial sums under the state mask: the 16 masked values a lane holds per
         // accumulator are first added in fp32 by a fixed balanced tree (4 more roundings on top of a 32-term
         // chain), then ONE fp64 add per accumulator -- fp64 instructions are the expensive ones here
