@@ -416,6 +416,9 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
     };
 
     unsigned long long accepted = 0;
+#ifdef MI_K2_PROFILE
+    unsigned long long tick_ = __builtin_amdgcn_s_memtime(), t_pre = 0, t_loop = 0, t_apply = 0, t_init = 0;
+#endif
     const float min_sz = (float)a.min_size;
     const bool use_min = a.min_size > 0;                     // wave-uniform
     // w mod (K-1) for a 32-bit w without the 40-instruction integer division: q = mulhi(w, floor(2^32/d)) is
@@ -445,6 +448,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             asm volatile("" ::: "memory");
             SlotAdj cur;
             if constexpr (PF) { cur = nxt; nxt = fetch_adj(t + 1); } else { cur = fetch_adj(t); }
+            K2_TICK(t_init);
             float thr = neglog_u(w0c) * T;
             if (i >= n) thr = -INFINITY;
             const int la = lab[i];
@@ -463,16 +467,19 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                     hb = hb + ((lj == lb) ? cur.val[k] : 0.0f);
                 }
             };
+            K2_TICK(t_pre);
             sum_h();
-            float fa = (float)(__shfl(cntv, la, 64) - 1), fb = (float)__shfl(cntv, lb, 64);
+            K2_TICK(t_apply);
+            int ia = __shfl(cntv, la, 64) - 1, ib = __shfl(cntv, lb, 64);      // sizes of this lane's two clusters
             const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
             uint64_t todo = ~0ull, flipped = 0ull;
             asm volatile("" ::"v"(metav), "v"(e01.x), "v"(e01.z), "v"(e23.x), "v"(e23.z));
             while (true) {
+                const float fa = (float)ia, fb = (float)ib;
                 const float ea = ha + a.c_pair * fa;
                 const float eb = hb + a.c_pair * fb;
                 const float dE = eb - ea;
-                // fa = (members of this lane's cluster) - 1: a move may not shrink a cluster below min_size
+                // ia = (members of this lane's cluster) - 1: a move may not shrink a cluster below min_size
                 const uint64_t m = (use_min ? __ballot(dE < thr && fa >= min_sz) : __ballot(dE < thr)) & todo;
                 if (m == 0) break;
                 const int l = __ffsll((unsigned long long)m) - 1;
@@ -480,10 +487,10 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                 flipped |= 1ull << l;
                 const int a_s = __builtin_amdgcn_readlane(la, l);
                 const int b_s = __builtin_amdgcn_readlane(lb, l);
-                if (lane == a_s) cntv -= 1;
-                if (lane == b_s) cntv += 1;
-                fa += (la == b_s ? 1.0f : 0.0f) - (la == a_s ? 1.0f : 0.0f);
-                fb += (lb == b_s ? 1.0f : 0.0f) - (lb == a_s ? 1.0f : 0.0f);
+                // integer sizes: compare + add-with-carry per term (the per-cluster table `cntv` is brought up
+                // to date once per slot, after the loop)
+                ia += (int)(la == b_s) - (int)(la == a_s);
+                ib += (int)(lb == b_s) - (int)(lb == a_s);
                 if ((has_in >> l) & 1ull) {                  // wave-uniform: l has neighbours inside this slot
                     if (lane == l) lab[i] = (uint8_t)lb;
                     const int nin = (int)(__builtin_amdgcn_readlane((int)metav, l) & 0xff);
@@ -497,10 +504,22 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             }
             if (flipped) {                                   // wave-uniform
                 accepted += (unsigned long long)__popcll(flipped);
-                if ((flipped >> lane) & 1ull) lab[i] = (uint8_t)lb;
+                const bool moved = (flipped >> lane) & 1ull;
+                if (moved) lab[i] = (uint8_t)lb;
+                // cluster sizes: lane q owns cnt[q]
+                for (int q = 0; q < K; ++q) {
+                    const int d = __popcll(__ballot(moved && lb == q)) - __popcll(__ballot(moved && la == q));
+                    if (lane == q) cntv += d;
+                }
             }
+            K2_TICK(t_loop);
         }
     }
+#ifdef MI_K2_PROFILE
+    if (lane == 0) {
+        atomicAdd(&a.stats[8], t_pre); atomicAdd(&a.stats[9], t_loop); atomicAdd(&a.stats[11], t_apply); atomicAdd(&a.stats[12], t_init);
+    }
+#endif
 
     // ---- epilogue: labels out, exact fp64 energy ----
     uint16_t *dst = static_cast<uint16_t *>(a.states) + (size_t)r * n;
