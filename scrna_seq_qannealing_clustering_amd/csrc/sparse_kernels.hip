@@ -471,26 +471,38 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             sum_h();
             K2_TICK(t_apply);
             int ia = __shfl(cntv, la, 64) - 1, ib = __shfl(cntv, lb, 64);      // sizes of this lane's two clusters
+            // one-hot images of this lane's two labels (K <= 32): a move a_s -> b_s then updates the sizes with
+            // AND + bit-count on the vector unit alone, no compare results travelling through SGPRs
+            const uint32_t oa = 1u << (la & 31), ob = 1u << (lb & 31);
+            const bool onehot = K <= 32;                     // wave-uniform
             const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
             uint64_t todo = ~0ull, flipped = 0ull;
             asm volatile("" ::"v"(metav), "v"(e01.x), "v"(e01.z), "v"(e23.x), "v"(e23.z));
+            auto commit_loop = [&](auto use_min_c, auto onehot_c) {
+            constexpr bool UM = decltype(use_min_c)::value, OH = decltype(onehot_c)::value;
             while (true) {
                 const float fa = (float)ia, fb = (float)ib;
                 const float ea = ha + a.c_pair * fa;
                 const float eb = hb + a.c_pair * fb;
                 const float dE = eb - ea;
                 // ia = (members of this lane's cluster) - 1: a move may not shrink a cluster below min_size
-                const uint64_t m = (use_min ? __ballot(dE < thr && fa >= min_sz) : __ballot(dE < thr)) & todo;
+                const uint64_t m = (UM ? __ballot(dE < thr && fa >= min_sz) : __ballot(dE < thr)) & todo;
                 if (m == 0) break;
                 const int l = __ffsll((unsigned long long)m) - 1;
                 todo = (~0ull << l) << 1;
                 flipped |= 1ull << l;
-                const int a_s = __builtin_amdgcn_readlane(la, l);
-                const int b_s = __builtin_amdgcn_readlane(lb, l);
-                // integer sizes: compare + add-with-carry per term (the per-cluster table `cntv` is brought up
-                // to date once per slot, after the loop)
-                ia += (int)(la == b_s) - (int)(la == a_s);
-                ib += (int)(lb == b_s) - (int)(lb == a_s);
+                // integer sizes (the per-cluster table `cntv` is brought up to date once per slot, after the loop)
+                if constexpr (OH) {
+                    const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)oa, l);
+                    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)ob, l);
+                    ia += (int)__builtin_popcount(oa & sb) - (int)__builtin_popcount(oa & sa);
+                    ib += (int)__builtin_popcount(ob & sb) - (int)__builtin_popcount(ob & sa);
+                } else {
+                    const int a_s = __builtin_amdgcn_readlane(la, l);
+                    const int b_s = __builtin_amdgcn_readlane(lb, l);
+                    ia += (int)(la == b_s) - (int)(la == a_s);
+                    ib += (int)(lb == b_s) - (int)(lb == a_s);
+                }
                 if ((has_in >> l) & 1ull) {                  // wave-uniform: l has neighbours inside this slot
                     if (lane == l) lab[i] = (uint8_t)lb;
                     const int nin = (int)(__builtin_amdgcn_readlane((int)metav, l) & 0xff);
@@ -502,6 +514,53 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                     if (touched) sum_h();
                 }
             }
+            };
+            // the two wave-uniform switches select one of four straight-line copies of the loop (inside it they
+            // would be a ladder of taken branches on the serial path)
+            if (!use_min && onehot && has_in == 0ull) {
+                // The common case -- no size constraint, K <= 32, no variable of this slot with a neighbour inside
+                // it (every slot under the slot-independent order) -- hand-scheduled like K2's loop: the lanes
+                // above the last mover are selected by EXEC, the two cluster ids of the mover travel as one-hot
+                // words through v_readlane, and the size updates are bit extracts.  18 VALU + 4 SALU per move.
+                float t0, t1;
+                int l_s;
+                uint32_t sa_s, sb_s;
+                asm volatile(
+                    "0:\n\t"
+                    "v_cvt_f32_i32 %[t0], %[ia]\n\t"
+                    "v_cvt_f32_i32 %[t1], %[ib]\n\t"
+                    "v_mul_f32 %[t0], %[c], %[t0]\n\t"
+                    "v_mul_f32 %[t1], %[c], %[t1]\n\t"
+                    "v_add_f32 %[t0], %[ha], %[t0]\n\t"
+                    "v_add_f32 %[t1], %[hb], %[t1]\n\t"
+                    "v_sub_f32 %[t0], %[t1], %[t0]\n\t"
+                    "v_cmp_lt_f32 vcc, %[t0], %[thr]\n\t"
+                    "s_cbranch_vccz 1f\n\t"
+                    "s_ff1_i32_b64 %[l], vcc\n\t"
+                    "s_bitset1_b64 %[fl], %[l]\n\t"
+                    "s_lshl_b64 exec, -2, %[l]\n\t"
+                    "s_nop 1\n\t"                              // SALU-written lane select: 4 wait states
+                    "v_readlane_b32 %[sa], %[oa], %[l]\n\t"
+                    "v_readlane_b32 %[sb], %[ob], %[l]\n\t"
+                    "s_nop 1\n\t"
+                    "v_bfe_u32 %[t0], %[sb], %[la], 1\n\t"      // [la == b_s]
+                    "v_bfe_u32 %[t1], %[sa], %[la], 1\n\t"      // [la == a_s]
+                    "v_sub_u32 %[t0], %[t0], %[t1]\n\t"
+                    "v_add_u32 %[ia], %[ia], %[t0]\n\t"
+                    "v_bfe_u32 %[t0], %[sb], %[lb], 1\n\t"
+                    "v_bfe_u32 %[t1], %[sa], %[lb], 1\n\t"
+                    "v_sub_u32 %[t0], %[t0], %[t1]\n\t"
+                    "v_add_u32 %[ib], %[ib], %[t0]\n\t"
+                    "s_branch 0b\n"
+                    "1:\n\t"
+                    "s_mov_b64 exec, -1\n\t"
+                    : [ia] "+v"(ia), [ib] "+v"(ib), [fl] "+s"(flipped), [t0] "=&v"(t0), [t1] "=&v"(t1), [l] "=&s"(l_s),
+                      [sa] "=&s"(sa_s), [sb] "=&s"(sb_s)
+                    : [c] "s"(a.c_pair), [ha] "v"(ha), [hb] "v"(hb), [thr] "v"(thr), [oa] "v"(oa), [ob] "v"(ob), [la] "v"(la),
+                      [lb] "v"(lb)
+                    : "vcc", "scc");
+            } else if (use_min) { if (onehot) commit_loop(std::true_type{}, std::true_type{}); else commit_loop(std::true_type{}, std::false_type{}); }
+            else { if (onehot) commit_loop(std::false_type{}, std::true_type{}); else commit_loop(std::false_type{}, std::false_type{}); }
             if (flipped) {                                   // wave-uniform
                 accepted += (unsigned long long)__popcll(flipped);
                 const bool moved = (flipped >> lane) & 1ull;
