@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
     // w mod (K-1) for a 32-bit w without the 40-instruction integer division: q = mulhi(w, floor(2^32/d)) is
     // floor(w/d) or one less, so the remainder needs at most one correction (d = K-1 <= 63)
     const uint32_t dK = (uint32_t)(K > 1 ? K - 1 : 1);
-    const uint32_t magic = (uint32_t)(0x100000000ull / dK);
+    const uint32_t magic = dK == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / dK);   // (2^32 does not fit for d = 1)
     for (int s = 0; s < a.num_sweeps && K > 1; ++s) {
         const float T = __int_as_float(__builtin_amdgcn_readfirstlane(
             __float_as_int(a.temps[a.temps_per_replica ? r : s])));

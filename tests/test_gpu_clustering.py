@@ -96,3 +96,35 @@ def test_clustering_dqm_returns_sampleset_for_plotting():
     import networkx as nx
     nx.set_node_attributes(G, dict(ss.first.sample), name="label1")
     assert all(d["label1"] in (0, 1, 2) for _, d in G.nodes(data=True))
+
+
+def test_main_py_shaped_entry_writes_labelled_graphs(tmp_path, capsys):
+    """`python -m scrna_seq_qannealing_clustering_amd.run`: main.py's blocks (graph import -> method ->
+    plot_and_save_*) on the circles fixture written as GEXF; the output files carry the attribute contract."""
+    import json
+    import networkx as nx
+    from scrna_seq_qannealing_clustering_amd import outputs, run
+    fx = load_fixture("noisy_circles")
+    src = tmp_path / "in.gexf"
+    nx.write_gexf(fx.graph(), src)
+    random.seed(3)
+    rc = run.main(["--graph", str(src), "--out", str(tmp_path), "--method", "bqm", "--method", "dqm",
+                   "--method", "subsampling_2", "--terminate-on", "once", "--num-of-clusters", "2",
+                   "--num-reads", "64", "--num-sweeps", "1000", "--seed", "1234"])
+    assert rc == 0
+    recs = {r["method"]: r for r in map(json.loads, capsys.readouterr().out.strip().splitlines())}
+    assert set(recs) == {"bqm", "dqm", "subsampling_2"}
+    assert recs["bqm"]["cut_edges"] == 0 and recs["bqm"]["uncut_edges"] == 2382      # the two circles
+    assert recs["bqm"]["components"] == [128, 128]
+    dirs = outputs.define_dirs(256, 5, 15, 15, 0.005, 0.05, "", 1, root=str(tmp_path))
+    assert recs["bqm"]["out"] == dirs["graph_out_bqm"]
+    H = nx.read_gexf(dirs["graph_out_bqm"])
+    assert list(H.nodes) == [str(v) for v in fx.nodes]
+    assert len({H.nodes[v]["label1"] for v in H.nodes}) == 2
+    D = nx.read_gexf(dirs["graph_out_dqm"])
+    assert sorted(recs["dqm"]["sizes"]) == [128, 128]
+    assert all(D.nodes[u]["label1"] == D.nodes[v]["label1"] for u, v in D.edges)     # no edge is cut
+    P = nx.read_gexf(dirs["graph_out_pru1"])
+    kept = [v for v in P.nodes if P.nodes[v]["label1"] == 1]
+    assert len(kept) == recs["subsampling_2"]["kept"] > 0
+    assert not any(P.has_edge(u, v) for i, u in enumerate(kept) for v in kept[i + 1:])   # an independent set

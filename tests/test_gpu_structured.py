@@ -198,7 +198,8 @@ def test_csr_rank1_hot_schedule_and_launch_shapes():
         assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("name,K", [("noisy_circles", 3), ("blobs", 3), ("aniso", 8), ("no_structure", 15)])
+@pytest.mark.parametrize("name,K", [("noisy_circles", 3), ("blobs", 3), ("aniso", 8), ("no_structure", 15),
+                                    ("noisy_moons", 2), ("varied", 33), ("noisy_circles", 64)])
 def test_potts_trajectory_parity(name, K):
     fx = load_fixture(name)
     pm = models.build_dqm_potts(fx.graph(), K, 0.005)
