@@ -296,3 +296,77 @@ def test_structured_error_behaviour():
     with pytest.raises(_lib.MiSaError) as ei:
         Problem.csr_rank1(rp, cc, np.ones(len(cc), dtype=np.float32), np.zeros(n, dtype=np.float32), 0.0)
     assert ei.value.code == -5
+
+
+def _csr_from_edges(n, edges, w):
+    """symmetric CSR (rows ascending by column) from an undirected edge list"""
+    rows = [[] for _ in range(n)]
+    for (u, v), x in zip(edges, w):
+        rows[u].append((v, x))
+        rows[v].append((u, x))
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    col, val = [], []
+    for i, r in enumerate(rows):
+        r.sort()
+        rowptr[i + 1] = rowptr[i] + len(r)
+        col += [c for c, _ in r]
+        val += [x for _, x in r]
+    return rowptr, np.asarray(col, dtype=np.int32), np.asarray(val, dtype=np.float32)
+
+
+def _edge_shapes():
+    rs = np.random.RandomState(12)
+    ring = lambda n: [(i, (i + 1) % n) for i in range(n)] if n > 2 else []
+    star = lambda n, hub, k: [(hub, j) for j in range(n) if j != hub][:k]
+    dense64 = [(i, j) for i in range(64) for j in range(i + 1, 64)]           # one full slot, degree 63
+    return {
+        "single_variable": (1, []),
+        "two_isolated": (2, []),
+        "one_full_slot_complete_graph": (64, dense64),
+        "slot_plus_one_no_edges": (65, []),
+        "ring_129": (129, ring(129)),
+        "hub_of_degree_64_at_a_slot_boundary": (200, star(200, 64, 64) + ring(200)[:50]),
+        "isolated_tail": (300, [(int(a), int(b)) for a, b in rs.randint(0, 100, size=(150, 2)) if a != b]),
+    }
+
+
+@pytest.mark.parametrize("shape", list(_edge_shapes()))
+@pytest.mark.parametrize("order", [None, "slots"])
+def test_structured_kernels_on_degenerate_graphs(shape, order):
+    """Empty / single-variable / one-slot / maximum-degree / isolated-node graphs through K2 and K3, natural
+    and slot-independent order, against the oracle (run on the same renumbered model)."""
+    n, edges = _edge_shapes()[shape]
+    edges = sorted(set((min(e), max(e)) for e in edges))
+    w = (np.random.RandomState(3).randint(1, 6, size=len(edges)) / 8.0).astype(np.float32)
+    rowptr, col, val = _csr_from_edges(n, edges, w)
+    lin = (np.random.RandomState(4).randint(-4, 5, size=n) / 4.0).astype(np.float32)
+    betas = np.geomspace(0.2, 8.0, 12)
+    R = 5
+    with Problem.csr_rank1(rowptr, col, -2.0 * val, lin, 0.25, order=order) as p:
+        p.anneal(R, betas, 21)
+        st, en, info = p.fetch()
+        perm = p.perm
+    if perm is None:
+        o_args = (rowptr, col, -2.0 * val, lin, 0.25)
+        back = slice(None)
+    else:
+        rp2, c2, v2 = models.permute_csr(rowptr, col, -2.0 * val, perm)
+        o_args = (rp2, c2, v2, lin[perm], 0.25)
+        back = np.argsort(perm)
+    ost, oen, ostats = so.sa_csr_rank1_philox(*o_args, R, betas, 21)
+    assert st.shape == (R, n) and np.array_equal(st, ost[:, back])
+    assert info["accepted"] == int(ostats[1]) and np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+
+    for K in (1, 2, 5):
+        with Problem.potts_csr(rowptr, col, -2.0 * val, 0.01, n, K, order=order) as p:
+            p.anneal(R, betas, 22)
+            lab, en, info = p.fetch()
+            perm = p.perm
+        if perm is None:
+            o_args, back = (rowptr, col, -2.0 * val, 0.01, n, K), slice(None)
+        else:
+            rp2, c2, v2 = models.permute_csr(rowptr, col, -2.0 * val, perm)
+            o_args, back = (rp2, c2, v2, 0.01, n, K), np.argsort(perm)
+        olab, oen, ostats = so.potts_csr_philox(*o_args, R, betas, 22)
+        assert lab.shape == (R, n) and np.array_equal(lab, olab[:, back])
+        assert info["accepted"] == int(ostats[1]) and np.allclose(en, oen, rtol=1e-9, atol=1e-9)
