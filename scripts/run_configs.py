@@ -116,4 +116,6 @@ out["config5_dqm_k15_n10605_tempering"] = {
     "snn_build_ms": g.timing}
 print(json.dumps(out["config5_dqm_k15_n10605_tempering"]), flush=True)
 
-json.dump(out, open(os.path.join(ROOT, "profiles", "r01_configs.json"), "w"), indent=1)
+for folder in ("profiles", "gpurun_out"):            # gpurun_out/ is what travels back from the GPU box
+    os.makedirs(os.path.join(ROOT, folder), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, folder, "r01_configs.json"), "w"), indent=1)
