@@ -73,6 +73,14 @@ int mi_sa_problem_create_potts_csr_f32(const int32_t *rowptr, const int32_t *col
                                        float c_pair, int n, int K, double lin_offset, int device,
                                        mi_sa_problem **out);
 
+/* Optional fp64 coefficients for the REPORTED energies of a structured problem (csr_rank1 / potts_csr).
+ * The chain always runs on the fp32 model given at creation; after this call the final energies
+ * (mi_sa_fetch, mi_sa_best) are evaluated on the device from these values instead, i.e. in the caller's own
+ * fp64 model -- what dimod's SampleSet.from_samples_bqm does on the host after the reference's sampler
+ * calls (BQM_clustering.py:57,75,85; DQM_clustering.py:45).  val: one double per stored CSR entry, in the
+ * order given at creation; lin: n doubles (csr_rank1; ignored for Potts, may be NULL). */
+int mi_sa_problem_set_energy_model_f64(mi_sa_problem *p, const double *val, const double *lin, double c_pair);
+
 int mi_sa_problem_destroy(mi_sa_problem *p);
 int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases, int *device);
 

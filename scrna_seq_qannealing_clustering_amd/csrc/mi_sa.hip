@@ -100,6 +100,9 @@ struct mi_sa_problem {
     float c_pair = 0.0f;
     uint32_t *d_ell_col = nullptr;
     float *d_ell_val = nullptr, *d_lin = nullptr;
+    double *d_ell_val64 = nullptr, *d_lin64 = nullptr;   // optional fp64 energy model (mi_sa_problem_set_energy_model_f64)
+    double c_pair64 = 0.0;
+    std::vector<int32_t> h_rowptr;           // structured kinds: the CSR row pointers given at creation
     uint2 *d_rows = nullptr;                 // K2: row-major adjacency, in-slot neighbours first
     uint32_t *d_meta = nullptr;              // K2: in-slot count | degree << 8
     uint4 *d_adj4 = nullptr;                 // K2: packed slot adjacency (see EllArgs::adj4)
@@ -356,6 +359,7 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
     HIP_TRY(hipMemcpy(p->d_ell_val, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
     p->slots = slots;
     p->D = D;
+    p->h_rowptr.assign(rowptr, rowptr + n + 1);
     {
         // row-major copy (K2, K3): neighbours in the variable's own 64-slot first
         std::vector<uint2> hr((size_t)slots * 64 * D);
@@ -453,12 +457,36 @@ int mi_sa_problem_create_potts_csr_f32(const int32_t *rowptr, const int32_t *col
     return MI_OK;
 }
 
+int mi_sa_problem_set_energy_model_f64(mi_sa_problem *p, const double *val, const double *lin, double c_pair)
+{
+    if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (p->kind != MI_KIND_CSR_RANK1 && p->kind != MI_KIND_POTTS_CSR)
+        return fail(MI_EUNSUPPORTED, "an fp64 energy model is defined for the structured kinds only");
+    const int n = p->n, D = p->D;
+    const int64_t nnz = p->h_rowptr.empty() ? 0 : p->h_rowptr[n];
+    if ((nnz > 0 && !val) || (p->kind == MI_KIND_CSR_RANK1 && !lin)) return fail(MI_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::vector<double> hv((size_t)p->slots * D * 64, 0.0), hl((size_t)p->slots * 64, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const int t = i >> 6, lane = i & 63;
+        for (int e = p->h_rowptr[i], k = 0; e < p->h_rowptr[i + 1]; ++e, ++k) hv[((size_t)t * D + k) * 64 + lane] = val[e];
+        if (lin) hl[i] = lin[i];
+    }
+    if (!p->d_ell_val64) HIP_TRY(hipMalloc((void **)&p->d_ell_val64, hv.size() * sizeof(double)));
+    if (!p->d_lin64) HIP_TRY(hipMalloc((void **)&p->d_lin64, hl.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(p->d_ell_val64, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_lin64, hl.data(), hl.size() * sizeof(double), hipMemcpyHostToDevice));
+    p->c_pair64 = c_pair;
+    return MI_OK;
+}
+
 int mi_sa_problem_destroy(mi_sa_problem *p)
 {
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -581,6 +609,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
         a.rows = p->d_rows; a.meta = p->d_meta; a.adj4 = p->d_adj4; a.slot_flags = p->d_slot_flags; a.state_bytes = p->k2_state_bytes; a.waves_override = p->opt_k2_waves; a.min_size = p->opt_min_cluster_size;
+        a.ell_val64 = p->d_ell_val64; a.lin64 = p->d_lin64; a.c_pair64 = p->c_pair64;
         if (p->kind == MI_KIND_POTTS_CSR && init) {
             // labels must be < K: validated on the host copy (the device trusts them as cnt[] indices)
             const uint16_t *l = static_cast<const uint16_t *>(init);

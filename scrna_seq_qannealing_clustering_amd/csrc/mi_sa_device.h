@@ -231,6 +231,10 @@ struct EllArgs {
     const uint32_t *slot_flags;// K2: per slot, non-zero when some variable of the slot has an in-slot neighbour
     int waves_override;        // (unused)
     int min_size;              // K3: a move out of a cluster with exactly min_size members is rejected (0 = off)
+    // optional fp64 coefficients for the final energies only (same layouts as ell_val / lin); null = use the fp32 model
+    const double *ell_val64;
+    const double *lin64;
+    double c_pair64;
 };
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_potts(const EllArgs &, hipStream_t);

@@ -342,15 +342,17 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         double acc = 0.0;
         for (int k = 0; k < D; ++k) {
             const uint32_t cc = a.ell_col[((size_t)t * D + k) * 64 + lane];
-            const float vv = a.ell_val[((size_t)t * D + k) * 64 + lane];
+            const size_t at = ((size_t)t * D + k) * 64 + lane;
+            const double vv = a.ell_val64 ? a.ell_val64[at] : (double)a.ell_val[at];
             const bool xc = XB ? (lds[cc] != 0) : (bool)((xm[cc >> 6] >> (cc & 63u)) & 1ull);
-            if (xc) acc += (double)vv;
+            if (xc) acc += vv;
         }
-        e += (double)a.lin[i] + 0.5 * acc;
+        e += (a.lin64 ? a.lin64[i] : (double)a.lin[i]) + 0.5 * acc;
     }
     e = wave_sum_f64(e);
     if (lane == 0) {
-        a.energy[r] = e + (double)a.c_pair * 0.5 * (double)cnt * (double)(cnt - 1) + a.offset;
+        const double cp = a.ell_val64 ? a.c_pair64 : (double)a.c_pair;
+        a.energy[r] = e + cp * 0.5 * (double)cnt * (double)(cnt - 1) + a.offset;
         atomicAdd(&a.stats[1], accepted);
     }
 }
@@ -590,11 +592,12 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
         dst[i] = (uint16_t)li;
         for (int k = 0; k < D; ++k) {
             const uint32_t cc = a.ell_col[((size_t)t * D + k) * 64 + lane];
-            const float vv = a.ell_val[((size_t)t * D + k) * 64 + lane];
-            if ((int)cc > i && lab[cc] == li) e += (double)vv;
+            const size_t at = ((size_t)t * D + k) * 64 + lane;
+            const double vv = a.ell_val64 ? a.ell_val64[at] : (double)a.ell_val[at];
+            if ((int)cc > i && lab[cc] == li) e += vv;
         }
     }
-    if (lane < K) e += (double)a.c_pair * 0.5 * (double)cntv * (double)(cntv - 1);
+    if (lane < K) e += (a.ell_val64 ? a.c_pair64 : (double)a.c_pair) * 0.5 * (double)cntv * (double)(cntv - 1);
     e = wave_sum_f64(e);
     if (lane == 0) {
         a.energy[r] = e + a.offset;

@@ -42,15 +42,23 @@ class Problem:
 
     @classmethod
     def csr_rank1(cls, rowptr, col, val, lin, c_pair: float, offset: float = 0.0,
-                  device: int = 0, order: Optional[str] = None) -> "Problem":
+                  device: int = 0, order: Optional[str] = None, energy_model=None) -> "Problem":
         """``order="slots"`` renumbers the variables on the device so that the 64 variables a wavefront
         sweeps together are (as far as possible) mutually non-adjacent -- the kernel's integer fast path
         (models.slot_independent_order).  States go in and come out in the CALLER's order either way; the
-        chain is a different (equally valid) sweep order, so results differ from ``order=None`` runs."""
+        chain is a different (equally valid) sweep order, so results differ from ``order=None`` runs.
+
+        ``energy_model=(val64, lin64, c_pair64)``: the caller's fp64 coefficients (same CSR structure); the
+        reported energies are then evaluated on the device in that model (the chain itself runs in fp32)."""
         perm = None
+        val64 = lin64 = None
+        if energy_model is not None:
+            val64, lin64 = np.asarray(energy_model[0], dtype=np.float64), np.asarray(energy_model[1], dtype=np.float64)
         if order == "slots":
             from .models import permute_csr, slot_independent_order
             perm = slot_independent_order(rowptr, col)
+            if val64 is not None:
+                val64, lin64 = permute_csr(rowptr, col, val64, perm)[2], lin64[perm]
             rowptr, col, val = permute_csr(rowptr, col, val, perm)
             lin = np.asarray(lin)[perm]
         elif order is not None:
@@ -65,16 +73,24 @@ class Problem:
         _lib.check(lib.mi_sa_problem_create_csr_rank1_f32(
             _ptr(rowptr, C.c_int32), _ptr(col, C.c_int32), _ptr(val, C.c_float),
             _ptr(lin, C.c_float), float(c_pair), n, float(offset), int(device), C.byref(h)))
-        return cls(h, _lib.KIND_CSR_RANK1, n, 2, device, perm=perm)
+        prob = cls(h, _lib.KIND_CSR_RANK1, n, 2, device, perm=perm)
+        if val64 is not None:
+            prob._set_energy_model(val64, lin64, float(energy_model[2]), len(val))
+        return prob
 
     @classmethod
     def potts_csr(cls, rowptr, col, val, c_pair: float, n: int, num_cases: int,
-                  lin_offset: float = 0.0, device: int = 0, order: Optional[str] = None) -> "Problem":
-        """``order="slots"``: as in :meth:`csr_rank1` (labels go in and come out in the caller's order)."""
+                  lin_offset: float = 0.0, device: int = 0, order: Optional[str] = None,
+                  energy_model=None) -> "Problem":
+        """``order="slots"``: as in :meth:`csr_rank1` (labels go in and come out in the caller's order).
+        ``energy_model=(val64, c_pair64)``: fp64 coefficients for the reported energies."""
         perm = None
+        val64 = None if energy_model is None else np.asarray(energy_model[0], dtype=np.float64)
         if order == "slots":
             from .models import permute_csr, slot_independent_order
             perm = slot_independent_order(rowptr, col)
+            if val64 is not None:
+                val64 = permute_csr(rowptr, col, val64, perm)[2]
             rowptr, col, val = permute_csr(rowptr, col, val, perm)
         elif order is not None:
             raise ValueError("order must be None or 'slots'")
@@ -86,7 +102,23 @@ class Problem:
         _lib.check(lib.mi_sa_problem_create_potts_csr_f32(
             _ptr(rowptr, C.c_int32), _ptr(col, C.c_int32), _ptr(val, C.c_float), float(c_pair),
             int(n), int(num_cases), float(lin_offset), int(device), C.byref(h)))
-        return cls(h, _lib.KIND_POTTS_CSR, int(n), int(num_cases), device, perm=perm)
+        prob = cls(h, _lib.KIND_POTTS_CSR, int(n), int(num_cases), device, perm=perm)
+        if val64 is not None:
+            prob._set_energy_model(val64, None, float(energy_model[1]), len(val))
+        return prob
+
+    def _set_energy_model(self, val64, lin64, c_pair64, nnz):
+        if len(val64) != nnz or (lin64 is not None and len(lin64) != self.n):
+            self.close()
+            raise ValueError("energy_model must have the structure of the fp32 model")
+        val64 = np.ascontiguousarray(val64, dtype=np.float64)
+        lin64 = None if lin64 is None else np.ascontiguousarray(lin64, dtype=np.float64)
+        try:
+            _lib.check(_lib.load().mi_sa_problem_set_energy_model_f64(
+                self._h, _ptr(val64, C.c_double), None if lin64 is None else _ptr(lin64, C.c_double), float(c_pair64)))
+        except Exception:
+            self.close()
+            raise
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):

@@ -230,7 +230,8 @@ class MI355XSampler:
         if use_csr:
             prob = Problem.csr_rank1(model.rowptr, model.col, model.val.astype(np.float32),
                                      model.lin.astype(np.float32), float(np.float32(model.c_pair)),
-                                     offset=model.offset, device=self.device, order="slots")
+                                     offset=model.offset, device=self.device, order="slots",
+                                     energy_model=(model.val, model.lin, model.c_pair))
         else:
             prob = Problem.dense(_symmetric_f32(model.dense_Qs()), offset=model.offset,
                                  device=self.device)
@@ -248,9 +249,10 @@ class MI355XSampler:
             states, dev_energy, stats = prob.fetch()
             kernel_ms = prob.kernel_ms()
             t2 = time.perf_counter()
-        # fp64 re-evaluation against the caller's fp64 coefficients (what dimod's
-        # SampleSet.from_samples_bqm does on the host); device fp32-model energies kept in info
-        energies = model.energies(states)
+        # energies in the caller's fp64 coefficients (what dimod's SampleSet.from_samples_bqm evaluates on the
+        # host): the structured kernel evaluates them itself (energy_model above); the dense kernels report
+        # the energies of the fp32 matrix they anneal, so that path re-evaluates here
+        energies = dev_energy if use_csr else model.energies(states)
         samples = states.astype(np.int8)
         if vartype == "SPIN":
             samples = 2 * samples - 1
@@ -261,6 +263,7 @@ class MI355XSampler:
             "timing": {"upload_s": t1 - t0, "anneal_s": t2 - t1, "kernel_ms": kernel_ms},
             "updates_per_s": (stats["proposals"] / (kernel_ms * 1e-3)) if kernel_ms > 0 else None,
             "accepted": stats["accepted"], "proposals": stats["proposals"],
+            "energy_evaluation": "device fp64 (caller's coefficients)" if use_csr else "host fp64",
             "device_energy_max_abs_diff": float(np.max(np.abs(dev_energy - energies))),
             "ignored_kwargs": ignored,
         }
@@ -280,7 +283,8 @@ class MI355XSampler:
         betas, beta_range, stype = self._schedule(kw, lambda: default_potts_beta_range(model))
         prob = Problem.potts_csr(model.rowptr, model.col, model.val.astype(np.float32),
                                  float(np.float32(model.c_pair)), n, model.num_cases,
-                                 lin_offset=model.lin_offset, device=self.device, order="slots")
+                                 lin_offset=model.lin_offset, device=self.device, order="slots",
+                                 energy_model=(model.val, model.c_pair))
         # the CQM's "every cluster has at least m members" (CQM_clustering.py:46-48): a hard constraint on moves
         min_size = int(kw.get("min_cluster_size", model.info.get("min_cluster_size", 0)) or 0)
         if min_size * model.num_cases > n:
@@ -301,7 +305,7 @@ class MI355XSampler:
             labels, dev_energy, stats = prob.fetch()
             kernel_ms = prob.kernel_ms()
             t2 = time.perf_counter()
-        energies = model.energies(labels)
+        energies = dev_energy                    # evaluated on the device in the model's fp64 coefficients
         info = {
             "beta_range": beta_range, "beta_schedule_type": stype, "seed": seed,
             "num_sweeps": int(len(betas)), "num_reads": int(num_reads), "kernel": "potts_csr",
@@ -309,7 +313,7 @@ class MI355XSampler:
             "timing": {"upload_s": t1 - t0, "anneal_s": t2 - t1, "kernel_ms": kernel_ms},
             "updates_per_s": (stats["proposals"] / (kernel_ms * 1e-3)) if kernel_ms > 0 else None,
             "accepted": stats["accepted"], "proposals": stats["proposals"],
-            "device_energy_max_abs_diff": float(np.max(np.abs(dev_energy - energies))),
+            "energy_evaluation": "device fp64 (caller's coefficients)",
             "ignored_kwargs": ignored,
         }
         return SampleSet(labels.astype(np.int32), energies, model.variables, "DISCRETE", info=info)

@@ -78,6 +78,27 @@ class SamplesArray(Sequence):
             yield SampleView(self._rows[r], self._variables, self._index)
 
 
+def _unique_rows(samples: np.ndarray):
+    """``np.unique(samples, axis=0, return_index=True, return_inverse=True)`` -- same rows, same
+    (lexicographic) order, same first-occurrence indices -- on a compact byte key per row: one bit per
+    variable for two-valued samples, one byte for small labels.  (The generic form compares rows field by
+    field: 0.2 s for 4096 x 2638 samples, more than the anneal that produced them.)"""
+    key = None
+    if samples.size and samples.dtype.kind in "iub":
+        lo, hi = samples.min(), samples.max()
+        if lo >= -1 and hi <= 1 and not (lo == -1 and np.any(samples == 0)):
+            # values within {0,1} or within {-1,+1}: the row order is the order of the "> 0" bits
+            key = np.packbits(samples > 0, axis=1)
+        elif lo >= 0 and hi < 256:
+            key = samples.astype(np.uint8)
+    if key is None:
+        return np.unique(samples, axis=0, return_index=True, return_inverse=True)
+    key = np.ascontiguousarray(key)
+    flat = key.view(np.dtype((np.void, key.shape[1]))).reshape(-1)
+    _, first, inverse = np.unique(flat, return_index=True, return_inverse=True)
+    return samples[first], first, inverse
+
+
 class SampleSet:
     def __init__(self, samples: np.ndarray, energies: np.ndarray, variables: List[Hashable],
                  vartype: str = "BINARY", num_occurrences: Optional[np.ndarray] = None,
@@ -95,8 +116,7 @@ class SampleSet:
                else np.asarray(num_occurrences, dtype=np.int64))
         extra = dict(extra or {})
         if aggregate and len(energies) > 1:
-            uniq, first, inverse = np.unique(samples, axis=0, return_index=True,
-                                             return_inverse=True)
+            uniq, first, inverse = _unique_rows(samples)
             inverse = np.asarray(inverse).reshape(-1)
             occ = np.bincount(inverse, weights=occ, minlength=len(first)).astype(np.int64)
             samples, energies = uniq, energies[first]

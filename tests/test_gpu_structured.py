@@ -370,3 +370,37 @@ def test_structured_kernels_on_degenerate_graphs(shape, order):
         olab, oen, ostats = so.potts_csr_philox(*o_args, R, betas, 22)
         assert lab.shape == (R, n) and np.array_equal(lab, olab[:, back])
         assert info["accepted"] == int(ostats[1]) and np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+
+
+def test_reported_energies_in_the_callers_fp64_model():
+    """mi_sa_problem_set_energy_model_f64: the chain runs on the fp32 model, the energies come back evaluated
+    on the device in the fp64 coefficients -- equal to the host's fp64 evaluation of the same states to
+    rounding (1e-12 relative), in both orders; the states themselves do not change."""
+    fx = load_fixture("aniso")
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    betas = models.make_beta_schedule(60, models.default_beta_range(m))
+    f32_args = (m.rowptr, m.col, f32(m.val), f32(m.lin), float(np.float32(m.c_pair)))
+    for order in (None, "slots"):
+        with Problem.csr_rank1(*f32_args, offset=m.offset, order=order) as p:
+            p.anneal(9, betas, 5)
+            st0, en0, _ = p.fetch()
+        with Problem.csr_rank1(*f32_args, offset=m.offset, order=order,
+                               energy_model=(m.val, m.lin, m.c_pair)) as p:
+            p.anneal(9, betas, 5)
+            st, en, _ = p.fetch()
+            best = p.best()
+        assert np.array_equal(st, st0)
+        want = m.energies(st)
+        assert np.allclose(en, want, rtol=1e-12, atol=1e-9)
+        assert not np.array_equal(en, en0) and np.allclose(en, en0, rtol=1e-5)      # fp32-model energies differ
+        assert best[1] == pytest.approx(want.min(), rel=1e-12)
+    pm = models.build_dqm_potts(fx.graph(), 4, 0.005)
+    pb = models.make_beta_schedule(40, (0.5, 30.0))
+    for order in (None, "slots"):
+        with Problem.potts_csr(pm.rowptr, pm.col, f32(pm.val), float(np.float32(pm.c_pair)), 256, 4,
+                               lin_offset=pm.lin_offset, order=order, energy_model=(pm.val, pm.c_pair)) as p:
+            p.anneal(6, pb, 8)
+            lab, en, _ = p.fetch()
+        assert np.allclose(en, pm.energies(lab), rtol=1e-12, atol=1e-9)
+    with pytest.raises(ValueError):
+        Problem.csr_rank1(*f32_args, energy_model=(m.val[:-1], m.lin, m.c_pair))

@@ -55,3 +55,25 @@ def test_vartype_change_and_errors():
 def test_discrete_labels_kept():
     ss = SampleSet(np.array([[0, 2, 300]]), np.array([1.5]), [0, 1, 2], "DISCRETE")
     assert ss.first.sample[2] == 300
+
+
+def test_row_aggregation_key_equals_numpy_unique():
+    """The compact-key aggregation returns exactly np.unique(axis=0)'s rows, order and indices."""
+    from scrna_seq_qannealing_clustering_amd.sampleset import _unique_rows
+    rs = np.random.RandomState(0)
+    cases = {
+        "binary": rs.randint(0, 2, (300, 37)).astype(np.int8),
+        "binary_with_duplicates": rs.randint(0, 2, (500, 5)).astype(np.int8),
+        "spin": (2 * rs.randint(0, 2, (500, 6)) - 1).astype(np.int8),
+        "labels": rs.randint(0, 5, (500, 4)).astype(np.int32),
+        "large_labels": rs.randint(0, 1000, (500, 2)).astype(np.int32),
+        "mixed_signs": rs.randint(-1, 2, (200, 3)).astype(np.int8),
+        "no_columns": np.zeros((4, 0), dtype=np.int8),
+        "all_minus_one": -np.ones((5, 3), dtype=np.int8),
+    }
+    for name, X in cases.items():
+        want = np.unique(X, axis=0, return_index=True, return_inverse=True)
+        got = _unique_rows(X)
+        assert np.array_equal(want[0], got[0]), name
+        assert np.array_equal(np.ravel(want[1]), np.ravel(got[1])), name
+        assert np.array_equal(np.ravel(want[2]), np.ravel(got[2])), name
