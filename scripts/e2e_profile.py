@@ -50,3 +50,29 @@ if "--dict" in sys.argv:
     t7 = time.perf_counter()
     print("reference-style dict: build %.3f s (the reference's own cost), sample_qubo(dict) %.3f s, E = %.4f"
           % (t6 - t5, t7 - t6, ss2.first.energy))
+
+# the k-way call (DQM_clustering.py:45) and the dict lifting, profiled the same way
+from scrna_seq_qannealing_clustering_amd import build_dqm_potts            # noqa: E402
+t8 = time.perf_counter()
+pm = build_dqm_potts(G, 8, 0.005)
+t9 = time.perf_counter()
+pr = cProfile.Profile()
+pr.enable()
+sd = s.sample_dqm(pm, num_reads=4096, num_sweeps=1000, seed=1234)
+_ = sd.first
+pr.disable()
+t10 = time.perf_counter()
+print("build_dqm_potts %.3f s, sample_dqm(4096 x 1000) %.3f s (kernel %.1f ms), E = %.4f"
+      % (t9 - t8, t10 - t9, sd.info["timing"]["kernel_ms"], sd.first.energy))
+out = io.StringIO()
+pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(10)
+print(out.getvalue()[:3500])
+if "--dict" in sys.argv:
+    pr = cProfile.Profile()
+    pr.enable()
+    from scrna_seq_qannealing_clustering_amd import qubo_dict_to_model
+    qm = qubo_dict_to_model(Q)
+    pr.disable()
+    out = io.StringIO()
+    pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(12)
+    print(out.getvalue()[:4000])

@@ -286,19 +286,16 @@ def qubo_dict_to_model(Q: Dict[Tuple[Hashable, Hashable], float], offset: float 
     dict's iteration order (u before v), as ``dimod.BinaryQuadraticModel.from_qubo`` would add them.
     If at least half of all pairs carry the same non-zero coefficient it is split off as the
     uniform pair term ``c_pair`` (the ``2 gamma`` of BQM_clustering.py:46-47), leaving S sparse."""
-    index: Dict[Hashable, int] = {}
-    us, vs, bs = [], [], []
-    for (u, v), b in Q.items():
-        iu = index.setdefault(u, len(index))
-        iv = index.setdefault(v, len(index))
-        us.append(iu)
-        vs.append(iv)
-        bs.append(b)
-    n = len(index)
-    variables = list(index.keys())
-    us = np.asarray(us, dtype=np.int64)
-    vs = np.asarray(vs, dtype=np.int64)
-    bs = np.asarray(bs, dtype=np.float64)
+    # the dict has n(n+1)/2 entries in the reference's models (3.5 M at n = 2638): everything per entry runs
+    # inside C iterators (dict.fromkeys keeps first-appearance order; map/fromiter do the label lookups)
+    from itertools import chain
+    m = len(Q)
+    variables = list(dict.fromkeys(chain.from_iterable(Q.keys())))
+    index: Dict[Hashable, int] = {v: i for i, v in enumerate(variables)}
+    n = len(variables)
+    flat = np.fromiter(map(index.__getitem__, chain.from_iterable(Q.keys())), dtype=np.int64, count=2 * m)
+    us, vs = flat[0::2], flat[1::2]
+    bs = np.fromiter(Q.values(), dtype=np.float64, count=m)
     lin = np.zeros(n, dtype=np.float64)
     diag = us == vs
     np.add.at(lin, us[diag], bs[diag])
@@ -315,14 +312,22 @@ def qubo_dict_to_model(Q: Dict[Tuple[Hashable, Hashable], float], offset: float 
         if counts[top] * 2 >= npairs and vals[top] != 0.0 and len(np.unique(key)) == len(key):
             c_pair = float(vals[top])
     if c_pair != 0.0:
-        # pairs absent from the dict have coefficient 0 => sparse part -c_pair there
-        dense_pairs = np.zeros((n, n), dtype=np.float64)
-        dense_pairs[lo, hi] = pb
-        iu, ju = np.triu_indices(n, 1)
-        resid = dense_pairs[iu, ju] - c_pair
-        nz = resid != 0.0
-        rowptr, col, val = _csr_from_edges(n, iu[nz].astype(np.int32), ju[nz].astype(np.int32),
-                                           resid[nz])
+        # sparse part = what is left of each pair after the uniform term (the entries are unique pairs here)
+        sel = pb != c_pair
+        su, sv, sr = lo[sel], hi[sel], pb[sel] - c_pair
+        if len(pb) < npairs:
+            # pairs absent from the dict have coefficient 0 => sparse part -c_pair there
+            present = np.zeros((n, n), dtype=bool)
+            present[lo, hi] = True
+            au, av = np.nonzero(~present & np.triu(np.ones((n, n), dtype=bool), 1))
+            su, sv = np.concatenate([su, au]), np.concatenate([sv, av])
+            sr = np.concatenate([sr, np.full(len(au), -c_pair)])
+            order = np.lexsort((sv, su))                      # upper-triangular row-major, as before
+            su, sv, sr = su[order], sv[order], sr[order]
+        else:
+            order = np.lexsort((sv, su))
+            su, sv, sr = su[order], sv[order], sr[order]
+        rowptr, col, val = _csr_from_edges(n, su.astype(np.int32), sv.astype(np.int32), sr)
     else:
         rowptr, col, val = _csr_from_edges(n, lo.astype(np.int32), hi.astype(np.int32), pb)
     return QuboModel(variables, lin, rowptr, col, val, c_pair=c_pair, offset=float(offset),
