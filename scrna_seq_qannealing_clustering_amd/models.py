@@ -294,22 +294,24 @@ def qubo_dict_to_model(Q: Dict[Tuple[Hashable, Hashable], float], offset: float 
     index: Dict[Hashable, int] = {v: i for i, v in enumerate(variables)}
     n = len(variables)
     flat = np.fromiter(map(index.__getitem__, chain.from_iterable(Q.keys())), dtype=np.int64, count=2 * m)
-    us, vs = flat[0::2], flat[1::2]
+    us, vs = flat[0::2].copy(), flat[1::2].copy()
     bs = np.fromiter(Q.values(), dtype=np.float64, count=m)
     lin = np.zeros(n, dtype=np.float64)
     diag = us == vs
     np.add.at(lin, us[diag], bs[diag])
-    lo = np.minimum(us[~diag], vs[~diag])
-    hi = np.maximum(us[~diag], vs[~diag])
-    pb = bs[~diag]
+    off = ~diag
+    lo = np.minimum(us, vs)[off]
+    hi = np.maximum(us, vs)[off]
+    pb = bs[off]
     c_pair = 0.0
     npairs = n * (n - 1) // 2
     if detect_uniform and len(pb) and len(pb) * 2 >= npairs and npairs > 0:
         vals, counts = np.unique(pb, return_counts=True)
         top = int(np.argmax(counts))
         # merged (u,v)/(v,u) duplicates would break the "one entry per pair" assumption
-        key = lo * n + hi
-        if counts[top] * 2 >= npairs and vals[top] != 0.0 and len(np.unique(key)) == len(key):
+        seen = np.zeros(n * n, dtype=bool)               # (len(pb) >= npairs / 2, so this is O(len(pb)) bytes)
+        seen[lo * n + hi] = True
+        if counts[top] * 2 >= npairs and vals[top] != 0.0 and int(np.count_nonzero(seen)) == len(pb):
             c_pair = float(vals[top])
     if c_pair != 0.0:
         # sparse part = what is left of each pair after the uniform term (the entries are unique pairs here)
