@@ -404,3 +404,102 @@ def test_reported_energies_in_the_callers_fp64_model():
         assert np.allclose(en, pm.energies(lab), rtol=1e-12, atol=1e-9)
     with pytest.raises(ValueError):
         Problem.csr_rank1(*f32_args, energy_model=(m.val[:-1], m.lin, m.c_pair))
+
+
+def _potts_host_energy(rowptr, col, val64, c_pair, lin_offset, lab, K):
+    rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+    e = 0.5 * ((lab[:, rows] == lab[:, col]) * val64[None, :]).sum(axis=1)
+    for r in range(lab.shape[0]):
+        cnt = np.bincount(lab[r], minlength=K).astype(np.float64)
+        e[r] += c_pair * 0.5 * float(np.sum(cnt * (cnt - 1.0)))
+    return e + lin_offset
+
+
+def test_full_size_properties_config3_potts_k8():
+    """BASELINE config 3 at full size (n = 2638, K = 8, 4096 replicas) -- beyond what the oracle runs in
+    seconds, so checked through size-independent properties: the oracle on a slice of the replicas
+    (any replica's chain depends only on its global id), two half-shards == one run, a run cut into two
+    calls == one run, every label < K, reported energies == fp64 host evaluation of the returned labels,
+    cluster sizes sum to n."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    from scrna_seq_qannealing_clustering_amd.sampler import default_potts_beta_range
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(2638, 5, 15, 15, 9, seed=0)
+    pm = models.build_dqm_potts(graphs.EdgeListGraph(nodes, eu, ev, w), 8, 0.005)
+    n, K, R = 2638, 8, 4096
+    betas = models.make_beta_schedule(24, default_potts_beta_range(pm))
+    args = (pm.rowptr, pm.col, f32(pm.val), float(np.float32(pm.c_pair)), n, K)
+    with Problem.potts_csr(*args, lin_offset=pm.lin_offset, order="slots", energy_model=(pm.val, pm.c_pair)) as p:
+        p.anneal(R, betas, 1234)
+        lab, en, info = p.fetch()
+        perm = p.perm
+        p.anneal(R // 2, betas, 1234, replica_offset=R // 2)               # the upper half-shard alone
+        lab_hi, en_hi, _ = p.fetch()
+        p.anneal(R, betas[:10], 1234)                                      # the same run in two pieces
+        p.anneal(R, betas[10:], 1234, sweep_offset=10, continue_run=True)
+        lab_2, en_2, info_2 = p.fetch()
+    assert lab.shape == (R, n) and int(lab.max()) < K
+    assert np.array_equal(lab[R // 2:], lab_hi) and np.array_equal(en[R // 2:], en_hi)
+    assert np.array_equal(lab, lab_2) and np.array_equal(en, en_2)
+    assert info["proposals"] == R * len(betas) * n and 0 < info["accepted"] < info["proposals"]
+    pick = np.r_[0:8, R // 2 - 4:R // 2 + 4, R - 8:R]
+    want = _potts_host_energy(pm.rowptr, pm.col, pm.val, pm.c_pair, pm.lin_offset, lab[pick].astype(np.int64), K)
+    assert np.allclose(en[pick], want, rtol=1e-12, atol=1e-9)
+    # oracle on replicas 2044..2051 of the renumbered model
+    rp2, c2, v2 = models.permute_csr(pm.rowptr, pm.col, f32(pm.val), perm)
+    olab, oen, _ = so.potts_csr_philox(rp2, c2, v2, args[3], n, K, 8, betas, 1234, lin_offset=pm.lin_offset,
+                                       replica_offset=2044)
+    assert np.array_equal(lab[2044:2052], olab[:, np.argsort(perm)])
+
+
+def test_full_size_properties_config4_50k_cells():
+    """BASELINE config 4 at full size (n = 50 000 cells, 1024 replicas = one GPU's share of 8192) on the CSR
+    kernel, slot-independent order: oracle on two of the replicas, shard invariance, reported energies ==
+    fp64 host evaluation."""
+    n, R = 50000, 1024
+    rowptr, col, val, lin, c_pair = _sparse_ring_model(n, seed=7)
+    betas = np.geomspace(0.002, 0.5, 4)
+    val64, lin64 = val.astype(np.float64), lin.astype(np.float64)
+    with Problem.csr_rank1(rowptr, col, val, lin, c_pair, order="slots", energy_model=(val64, lin64, c_pair)) as p:
+        p.anneal(R, betas, 99)
+        st, en, info = p.fetch()
+        perm = p.perm
+        p.anneal(16, betas, 99, replica_offset=1000)
+        st_hi, en_hi, _ = p.fetch()
+    assert st.shape == (R, n) and info["proposals"] == R * len(betas) * n
+    assert np.array_equal(st[1000:1016], st_hi) and np.array_equal(en[1000:1016], en_hi)
+    pick = np.array([0, 511, 1023])
+    X = st[pick].astype(np.float64)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    s = X.sum(axis=1)
+    want = X @ lin64 + c_pair * 0.5 * s * (s - 1.0) + 0.5 * ((X[:, rows] * X[:, col]) * val64[None, :]).sum(axis=1)
+    assert np.allclose(en[pick], want, rtol=1e-12, atol=1e-6)
+    if perm is None:
+        o_args, back = (rowptr, col, val, lin, c_pair), slice(None)
+    else:
+        rp2, c2, v2 = models.permute_csr(rowptr, col, val, perm)
+        o_args, back = (rp2, c2, v2, lin[perm], c_pair), np.argsort(perm)
+    ost, _, _ = so.sa_csr_rank1_philox(*o_args, 2, betas, 99, replica_offset=700)
+    assert np.array_equal(st[700:702], ost[:, back])
+
+
+def test_full_size_properties_config5_kidney_k15():
+    """BASELINE config 5's model size (n = 10 605 cells, K = 15): one rung per replica (the tempering launch
+    shape), oracle on one replica, labels < K, energies == fp64 host evaluation."""
+    n, K, R = 10605, 15, 128
+    rowptr, col, val, _, _ = _sparse_ring_model(n, seed=11)
+    val = f32(val / 8.0)                                                  # -2 w, the DQM's edge bias
+    c_pair = float(np.float32(0.01))
+    betas = np.geomspace(0.5, 30.0, R)                                    # one constant beta per replica
+    with Problem.potts_csr(rowptr, col, val, c_pair, n, K, order="slots",
+                           energy_model=(val.astype(np.float64), c_pair)) as p:
+        p.anneal(R, betas, 31, num_sweeps=5)
+        lab, en, info = p.fetch()
+        perm = p.perm
+    assert lab.shape == (R, n) and int(lab.max()) < K and info["proposals"] == R * 5 * n
+    pick = np.array([0, 64, 127])
+    want = _potts_host_energy(rowptr, col, val.astype(np.float64), c_pair, 0.0, lab[pick].astype(np.int64), K)
+    assert np.allclose(en[pick], want, rtol=1e-12, atol=1e-9)
+    rp2, c2, v2 = (rowptr, col, val) if perm is None else models.permute_csr(rowptr, col, val, perm)
+    back = slice(None) if perm is None else np.argsort(perm)
+    olab, _, _ = so.potts_csr_philox(rp2, c2, v2, c_pair, n, K, 1, np.full(5, betas[77]), 31, replica_offset=77)
+    assert np.array_equal(lab[77:78], olab[:, back])
