@@ -322,9 +322,10 @@ int orc_potts_csr_philox_min(const int *rowptr, const int *col, const float *val
                     if (lj == a) ha = ha + val[e];
                     if (lj == b) hb = hb + val[e];
                 }
-                float ea = ha + c_pair * (float)(cnt[a] - 1);
-                float eb = hb + c_pair * (float)cnt[b];
-                float dE = eb - ea;
+                /* dE = (h_b + c cnt_b) - (h_a + c (cnt_a - 1)), evaluated as ONE fused multiply-add of the
+                 * (exact, integer) size difference onto the (fp32) field difference -- chain specification
+                 * 2c in DESIGN.md section 3; the device kernel evaluates the same expression */
+                float dE = fmaf(c_pair, (float)(cnt[b] - (cnt[a] - 1)), hb - ha);
                 float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
                 ++tot_prop;
                 if (dE < thr && cnt[a] - 1 >= min_size) {

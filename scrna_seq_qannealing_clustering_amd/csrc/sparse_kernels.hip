@@ -421,7 +421,6 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
 #ifdef MI_K2_PROFILE
     unsigned long long tick_ = __builtin_amdgcn_s_memtime(), t_pre = 0, t_loop = 0, t_apply = 0, t_init = 0;
 #endif
-    const float min_sz = (float)a.min_size;
     const bool use_min = a.min_size > 0;                     // wave-uniform
     // w mod (K-1) for a 32-bit w without the 40-instruction integer division: q = mulhi(w, floor(2^32/d)) is
     // floor(w/d) or one less, so the remainder needs at most one correction (d = K-1 <= 63)
@@ -482,13 +481,13 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             asm volatile("" ::"v"(metav), "v"(e01.x), "v"(e01.z), "v"(e23.x), "v"(e23.z));
             auto commit_loop = [&](auto use_min_c, auto onehot_c) {
             constexpr bool UM = decltype(use_min_c)::value, OH = decltype(onehot_c)::value;
+            float hd = hb - ha;
             while (true) {
-                const float fa = (float)ia, fb = (float)ib;
-                const float ea = ha + a.c_pair * fa;
-                const float eb = hb + a.c_pair * fb;
-                const float dE = eb - ea;
+                // dE = (h_b + c n_b) - (h_a + c (n_a - 1)) as one fma of the integer size difference onto the
+                // field difference (oracle 2c evaluates the same expression)
+                const float dE = fmaf(a.c_pair, (float)(ib - ia), hd);
                 // ia = (members of this lane's cluster) - 1: a move may not shrink a cluster below min_size
-                const uint64_t m = (UM ? __ballot(dE < thr && fa >= min_sz) : __ballot(dE < thr)) & todo;
+                const uint64_t m = (UM ? __ballot(dE < thr && ia >= a.min_size) : __ballot(dE < thr)) & todo;
                 if (m == 0) break;
                 const int l = __ffsll((unsigned long long)m) - 1;
                 todo = (~0ull << l) << 1;
@@ -513,7 +512,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                     if (nin > 2) touched |= lane == (int)(__builtin_amdgcn_readlane((int)e23.x, l) & 63);
                     if (nin > 3) touched |= lane == (int)(__builtin_amdgcn_readlane((int)e23.z, l) & 63);
                     for (int k = 4; k < nin; ++k) touched |= lane == (int)(rows[((size_t)t * 64 + l) * D + k].x & 63u);
-                    if (touched) sum_h();
+                    if (touched) { sum_h(); hd = hb - ha; }
                 }
             }
             };
@@ -522,45 +521,78 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             if (!use_min && onehot && has_in == 0ull) {
                 // The common case -- no size constraint, K <= 32, no variable of this slot with a neighbour inside
                 // it (every slot under the slot-independent order) -- hand-scheduled like K2's loop: the lanes
-                // above the last mover are selected by EXEC, the two cluster ids of the mover travel as one-hot
-                // words through v_readlane, and the size updates are bit extracts.  18 VALU + 4 SALU per move.
+                // above the last mover are selected by EXEC and each lane carries only the DIFFERENCE of its two
+                // cluster sizes.
                 float t0, t1;
                 int l_s;
                 uint32_t sa_s, sb_s;
-                asm volatile(
-                    "0:\n\t"
-                    "v_cvt_f32_i32 %[t0], %[ia]\n\t"
-                    "v_cvt_f32_i32 %[t1], %[ib]\n\t"
-                    "v_mul_f32 %[t0], %[c], %[t0]\n\t"
-                    "v_mul_f32 %[t1], %[c], %[t1]\n\t"
-                    "v_add_f32 %[t0], %[ha], %[t0]\n\t"
-                    "v_add_f32 %[t1], %[hb], %[t1]\n\t"
-                    "v_sub_f32 %[t0], %[t1], %[t0]\n\t"
-                    "v_cmp_lt_f32 vcc, %[t0], %[thr]\n\t"
-                    "s_cbranch_vccz 1f\n\t"
-                    "s_ff1_i32_b64 %[l], vcc\n\t"
-                    "s_bitset1_b64 %[fl], %[l]\n\t"
-                    "s_lshl_b64 exec, -2, %[l]\n\t"
-                    "s_nop 1\n\t"                              // SALU-written lane select: 4 wait states
-                    "v_readlane_b32 %[sa], %[oa], %[l]\n\t"
-                    "v_readlane_b32 %[sb], %[ob], %[l]\n\t"
-                    "s_nop 1\n\t"
-                    "v_bfe_u32 %[t0], %[sb], %[la], 1\n\t"      // [la == b_s]
-                    "v_bfe_u32 %[t1], %[sa], %[la], 1\n\t"      // [la == a_s]
-                    "v_sub_u32 %[t0], %[t0], %[t1]\n\t"
-                    "v_add_u32 %[ia], %[ia], %[t0]\n\t"
-                    "v_bfe_u32 %[t0], %[sb], %[lb], 1\n\t"
-                    "v_bfe_u32 %[t1], %[sa], %[lb], 1\n\t"
-                    "v_sub_u32 %[t0], %[t0], %[t1]\n\t"
-                    "v_add_u32 %[ib], %[ib], %[t0]\n\t"
-                    "s_branch 0b\n"
-                    "1:\n\t"
-                    "s_mov_b64 exec, -1\n\t"
-                    : [ia] "+v"(ia), [ib] "+v"(ib), [fl] "+s"(flipped), [t0] "=&v"(t0), [t1] "=&v"(t1), [l] "=&s"(l_s),
-                      [sa] "=&s"(sa_s), [sb] "=&s"(sb_s)
-                    : [c] "s"(a.c_pair), [ha] "v"(ha), [hb] "v"(hb), [thr] "v"(thr), [oa] "v"(oa), [ob] "v"(ob), [la] "v"(la),
-                      [lb] "v"(lb)
-                    : "vcc", "scc");
+                int idf = ib - ia;
+                const float hd = hb - ha;
+                if (K <= 16) {
+                    // the mover's clusters travel as 2 x their ids; W holds a signed 2-bit field per cluster
+                    // (+1 at the target, -1 at the source), so a lane's size change is one v_bfe_i32 per label:
+                    // 9 VALU + 8 SALU per move
+                    const int la2 = la * 2, lb2 = lb * 2;
+                    asm volatile(
+                        "0:\n\t"
+                        "v_cvt_f32_i32 %[t0], %[id]\n\t"
+                        "v_fma_f32 %[t0], %[c], %[t0], %[hd]\n\t"
+                        "v_cmp_lt_f32 vcc, %[t0], %[thr]\n\t"
+                        "s_cbranch_vccz 1f\n\t"
+                        "s_ff1_i32_b64 %[l], vcc\n\t"
+                        "s_bitset1_b64 %[fl], %[l]\n\t"
+                        "s_lshl_b64 exec, -2, %[l]\n\t"
+                        "s_nop 1\n\t"                          // SALU-written lane select: 4 wait states
+                        "v_readlane_b32 %[sa], %[la2], %[l]\n\t"
+                        "v_readlane_b32 %[sb], %[lb2], %[l]\n\t"
+                        "s_nop 0\n\t"
+                        "s_lshl_b32 %[sa], 3, %[sa]\n\t"        // -1 at the source cluster
+                        "s_lshl_b32 %[sb], 1, %[sb]\n\t"        // +1 at the target cluster
+                        "s_or_b32 %[sa], %[sa], %[sb]\n\t"
+                        "s_nop 0\n\t"
+                        "v_bfe_i32 %[t0], %[sa], %[lb2], 2\n\t"
+                        "v_bfe_i32 %[t1], %[sa], %[la2], 2\n\t"
+                        "v_sub_u32 %[t0], %[t0], %[t1]\n\t"
+                        "v_add_u32 %[id], %[id], %[t0]\n\t"
+                        "s_branch 0b\n"
+                        "1:\n\t"
+                        "s_mov_b64 exec, -1\n\t"
+                        : [id] "+v"(idf), [fl] "+s"(flipped), [t0] "=&v"(t0), [t1] "=&v"(t1), [l] "=&s"(l_s),
+                          [sa] "=&s"(sa_s), [sb] "=&s"(sb_s)
+                        : [c] "s"(a.c_pair), [hd] "v"(hd), [thr] "v"(thr), [la2] "v"(la2), [lb2] "v"(lb2)
+                        : "vcc", "scc");
+                } else {
+                    // 16 < K <= 32: one-hot images of the mover's clusters, four 1-bit extracts per move
+                    asm volatile(
+                        "0:\n\t"
+                        "v_cvt_f32_i32 %[t0], %[id]\n\t"
+                        "v_fma_f32 %[t0], %[c], %[t0], %[hd]\n\t"
+                        "v_cmp_lt_f32 vcc, %[t0], %[thr]\n\t"
+                        "s_cbranch_vccz 1f\n\t"
+                        "s_ff1_i32_b64 %[l], vcc\n\t"
+                        "s_bitset1_b64 %[fl], %[l]\n\t"
+                        "s_lshl_b64 exec, -2, %[l]\n\t"
+                        "s_nop 1\n\t"
+                        "v_readlane_b32 %[sa], %[oa], %[l]\n\t"
+                        "v_readlane_b32 %[sb], %[ob], %[l]\n\t"
+                        "s_nop 1\n\t"
+                        "v_bfe_u32 %[t0], %[sb], %[lb], 1\n\t"      // [lb == b_s]
+                        "v_bfe_u32 %[t1], %[sa], %[lb], 1\n\t"      // [lb == a_s]
+                        "v_sub_u32 %[t0], %[t0], %[t1]\n\t"
+                        "v_add_u32 %[id], %[id], %[t0]\n\t"
+                        "v_bfe_u32 %[t0], %[sb], %[la], 1\n\t"      // [la == b_s]
+                        "v_bfe_u32 %[t1], %[sa], %[la], 1\n\t"      // [la == a_s]
+                        "v_sub_u32 %[t0], %[t0], %[t1]\n\t"
+                        "v_sub_u32 %[id], %[id], %[t0]\n\t"
+                        "s_branch 0b\n"
+                        "1:\n\t"
+                        "s_mov_b64 exec, -1\n\t"
+                        : [id] "+v"(idf), [fl] "+s"(flipped), [t0] "=&v"(t0), [t1] "=&v"(t1), [l] "=&s"(l_s),
+                          [sa] "=&s"(sa_s), [sb] "=&s"(sb_s)
+                        : [c] "s"(a.c_pair), [hd] "v"(hd), [thr] "v"(thr), [oa] "v"(oa), [ob] "v"(ob), [la] "v"(la),
+                          [lb] "v"(lb)
+                        : "vcc", "scc");
+                }
             } else if (use_min) { if (onehot) commit_loop(std::true_type{}, std::true_type{}); else commit_loop(std::true_type{}, std::false_type{}); }
             else { if (onehot) commit_loop(std::false_type{}, std::true_type{}); else commit_loop(std::false_type{}, std::false_type{}); }
             if (flipped) {                                   // wave-uniform
