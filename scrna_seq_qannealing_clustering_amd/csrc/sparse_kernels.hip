@@ -379,7 +379,9 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
     if (r >= a.R) return;
     const uint32_t gid = a.replica_offset + (uint32_t)r;
     const int n = a.n, slots = a.slots, K = a.K;
-    uint8_t *lab = reinterpret_cast<uint8_t *>(lds) + (size_t)wave * slots * 64;
+    // LDS per wave: the labels (one byte per variable) and the K cluster sizes (one int each, 64 reserved)
+    uint8_t *lab = reinterpret_cast<uint8_t *>(lds) + (size_t)wave * ((size_t)slots * 64 + 256);
+    int *cnt = reinterpret_cast<int *>(lab + (size_t)slots * 64);
     const uint16_t *init = static_cast<const uint16_t *>(a.init);
     const uint2 *rows = a.rows;
 
@@ -403,6 +405,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             c += __popcll(__ballot(t * 64 + lane < n && lab[t * 64 + lane] == q));
         if (lane == q) cntv = c;
     }
+    cnt[lane] = cntv;
 
     constexpr bool PF = (D == 16);
     struct SlotAdj { uint32_t col[D]; float val[D]; };
@@ -471,7 +474,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             K2_TICK(t_pre);
             sum_h();
             K2_TICK(t_apply);
-            int ia = __shfl(cntv, la, 64) - 1, ib = __shfl(cntv, lb, 64);      // sizes of this lane's two clusters
+            int ia = cnt[la] - 1, ib = cnt[lb];              // sizes of this lane's two clusters
             // one-hot images of this lane's two labels (K <= 32): a move a_s -> b_s then updates the sizes with
             // AND + bit-count on the vector unit alone, no compare results travelling through SGPRs
             const uint32_t oa = 1u << (la & 31), ob = 1u << (lb & 31);
@@ -599,10 +602,11 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                 accepted += (unsigned long long)__popcll(flipped);
                 const bool moved = (flipped >> lane) & 1ull;
                 if (moved) lab[i] = (uint8_t)lb;
-                // cluster sizes: lane q owns cnt[q]
-                for (int q = 0; q < K; ++q) {
-                    const int d = __popcll(__ballot(moved && lb == q)) - __popcll(__ballot(moved && la == q));
-                    if (lane == q) cntv += d;
+                // cluster sizes: two LDS atomics per mover (the wave's LDS operations execute in order, so the
+                // next slot's reads of cnt[] see them)
+                if (moved) {
+                    __hip_atomic_fetch_add(&cnt[lb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&cnt[la], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
             K2_TICK(t_loop);
@@ -629,6 +633,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             if ((int)cc > i && lab[cc] == li) e += vv;
         }
     }
+    cntv = cnt[lane];
     if (lane < K) e += (a.ell_val64 ? a.c_pair64 : (double)a.c_pair) * 0.5 * (double)cntv * (double)(cntv - 1);
     e = wave_sum_f64(e);
     if (lane == 0) {
@@ -683,7 +688,7 @@ int mi_launch_csr_rank1(const EllArgs &a, hipStream_t st)
 
 int mi_launch_potts(const EllArgs &a, hipStream_t st)
 {
-    const size_t per_wave = (size_t)a.slots * 64;
+    const size_t per_wave = (size_t)a.slots * 64 + 256;      // labels + cluster sizes
     if (a.D == 16) return launch_sparse(k_anneal_potts<16>, a, per_wave, st);
     if (a.D == 32) return launch_sparse(k_anneal_potts<32>, a, per_wave, st);
     if (a.D == 64) return launch_sparse(k_anneal_potts<64>, a, per_wave, st);
