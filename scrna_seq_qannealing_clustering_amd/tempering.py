@@ -55,20 +55,20 @@ def exchange_step(energies: np.ndarray, rung: np.ndarray, ladder: np.ndarray, nu
     R = len(energies)
     chains = R // num_temps
     rung = rung.copy()
+    energies = np.asarray(energies, dtype=np.float64)
     holder = np.empty((chains, num_temps), dtype=np.int64)          # holder[c, k] = replica holding rung k
-    for g in range(R):
-        holder[g // num_temps, rung[g]] = g
+    g = np.arange(R)
+    holder[g // num_temps, rung] = g
     rs = np.random.RandomState([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF, rnd & 0x7FFFFFFF, 0x5157])
     u = rs.random_sample((chains, num_temps))
-    proposed = accepted = 0
-    for c in range(chains):
-        for k in range(rnd & 1, num_temps - 1, 2):
-            a, b = holder[c, k], holder[c, k + 1]
-            arg = (ladder[k] - ladder[k + 1]) * (energies[a] - energies[b])
-            proposed += 1
-            if arg >= 0.0 or u[c, k] < np.exp(arg):
-                rung[a], rung[b] = k + 1, k
-                accepted += 1
+    ks = np.arange(rnd & 1, num_temps - 1, 2)                       # disjoint pairs (k, k+1): all at once
+    a, b = holder[:, ks], holder[:, ks + 1]
+    arg = (ladder[ks] - ladder[ks + 1])[None, :] * (energies[a] - energies[b])
+    acc = (arg >= 0.0) | (u[:, ks] < np.exp(np.minimum(arg, 0.0)))
+    up = np.broadcast_to(ks[None, :], acc.shape)
+    rung[a[acc]] = up[acc] + 1
+    rung[b[acc]] = up[acc]
+    proposed, accepted = int(acc.size), int(np.count_nonzero(acc))
     return rung, proposed, accepted
 
 

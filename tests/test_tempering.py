@@ -163,3 +163,33 @@ def test_gpu_parallel_tempering_matches_oracle_engine_and_improves_on_sa():
     ids = {c: k for k, c in enumerate(sorted(set(comp.tolist())))}
     e_comp = pm.energies(np.array([[ids[int(c)] for c in comp]]))[0]
     assert out["best_energy"] <= e_comp * (1 - 1e-6)          # device energies use the fp32-stored coefficients
+
+
+def test_exchange_step_equals_the_pairwise_loop():
+    """The vectorised exchange phase against the plain loop over chains and neighbouring rungs."""
+    from scrna_seq_qannealing_clustering_amd.tempering import exchange_step
+    rs = np.random.RandomState(5)
+    for T, chains, rnd in ((2, 1, 0), (5, 7, 0), (5, 7, 1), (8, 16, 3), (3, 4, 2)):
+        R = T * chains
+        ladder = np.geomspace(0.3, 9.0, T)
+        energies = rs.normal(scale=3.0, size=R)
+        rung = np.concatenate([rs.permutation(T) for _ in range(chains)]).astype(np.int64)
+        seed = 77
+        got, gp, ga = exchange_step(energies, rung, ladder, T, rnd, seed)
+        want = rung.copy()
+        holder = np.empty((chains, T), dtype=np.int64)
+        for g in range(R):
+            holder[g // T, rung[g]] = g
+        u = np.random.RandomState([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF, rnd & 0x7FFFFFFF, 0x5157]
+                                  ).random_sample((chains, T))
+        p = acc = 0
+        for c in range(chains):
+            for k in range(rnd & 1, T - 1, 2):
+                a, b = holder[c, k], holder[c, k + 1]
+                arg = (ladder[k] - ladder[k + 1]) * (energies[a] - energies[b])
+                p += 1
+                if arg >= 0.0 or u[c, k] < np.exp(arg):
+                    want[a], want[b] = k + 1, k
+                    acc += 1
+        assert np.array_equal(got, want) and (gp, ga) == (p, acc)
+        assert np.array_equal(np.sort(got.reshape(chains, T), axis=1), np.tile(np.arange(T), (chains, 1)))
