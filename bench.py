@@ -47,6 +47,30 @@ def build_workload():
     return m, Qs, betas, (eu, ev, w), G
 
 
+def real_neal_probe(Qs, betas):
+    """if the real dwave-neal happens to be importable on this host, time it on a bounded
+    sample as well (probe only -- nothing is installed or fetched).  Returns None when it is absent."""
+    sampler = None
+    for mod, attr in (("neal", "SimulatedAnnealingSampler"), ("dwave.samplers", "SimulatedAnnealingSampler")):
+        try:
+            sampler = getattr(__import__(mod, fromlist=[attr]), attr)()
+            break
+        except Exception:
+            continue
+    if sampler is None:
+        return None
+    n = Qs.shape[0]
+    iu, ju = np.triu_indices(n, 1)
+    Q = {(int(i), int(i)): float(Qs[i, i]) for i in range(n)}
+    Q.update({(int(i), int(j)): 2.0 * float(Qs[i, j]) for i, j in zip(iu, ju) if Qs[i, j] != 0.0})
+    sweeps = 50
+    t0 = time.perf_counter()
+    ss = sampler.sample_qubo(Q, num_reads=4, num_sweeps=sweeps, beta_range=(float(betas[0]), float(betas[-1])), seed=SEED)
+    t = time.perf_counter() - t0
+    return {"value": 4 * sweeps * n / t, "unit": "spin-flip updates/s", "cores": 1, "seconds": t,
+            "best_energy": float(ss.first.energy), "sample": "real dwave-neal, 4 reads x %d sweeps, same Q" % sweeps}
+
+
 def cpu_baseline(Qs, betas, seconds_target=15.0):
     """The oracle's restatement of dwave-neal (Ising, fp64, xorshift128+, sequential sweeps) on a bounded
     sample of the SAME workload: same Q, every (len/sweeps)-th beta of the same schedule."""
@@ -80,6 +104,7 @@ def cpu_baseline(Qs, betas, seconds_target=15.0):
                   "(every %d-th beta of the 1000-sweep schedule), OpenMP over reads on %d threads; "
                   "real dwave-neal is not installable offline" % (reads, len(sub), max(1, len(betas) // sweeps), cores),
         "seconds": t,
+        "real_neal": real_neal_probe(Qs, betas),         # null: not importable on this host
     }
 
 
