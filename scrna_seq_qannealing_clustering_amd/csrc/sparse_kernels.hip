@@ -45,9 +45,6 @@ __device__ __forceinline__ void slot_words(uint32_t (&w)[4], int tg, int lane, u
 // v_readlane + one masked add per in-slot neighbour (0.36 per flip on the PBMC-sized SNN graph).  The flipped
 // lane is never tested again in this slot, so its own state is patched after the loop (x ^= flipped), and
 // the sign of a flip comes from the slot's state mask.  ~20 instructions per accepted flip.
-#ifndef MI_K2_LOOP
-#define MI_K2_LOOP 2
-#endif
 #ifdef MI_K2_PROFILE
 #define K2_TICK(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); var += now_ - tick_; tick_ = now_; } while (0)
 #else
@@ -210,33 +207,9 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
             K2_TICK(t_pre);
             // The serial loop, hand-scheduled: with four wavefronts per SIMD it is bound by SCALAR issue (one
             // SALU instruction per SIMD every four cycles), and hipcc spends 16 scalar instructions per flip
-            // on it.  Here: 5 SALU + 3 VALU.  q = (s - s0) - lo per lane; the flipped lane's +-1 reaches
-            // every lane through v_readlane; todo = lanes above the last flipped one.
+            // on it.  q = (s - s0) - lo per lane.
             unsigned int q = (unsigned int)(0 - lo);
             int l_s, d_s;
-#if MI_K2_LOOP == 1
-            // first form: todo mask in SGPRs, the flipped lane's +-1 through v_readlane (5 SALU + 3 VALU)
-            const int delta = xi ? -1 : 1;
-            uint64_t m;
-            asm volatile(
-                "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
-                "s_and_b64 %[m], vcc, %[todo]\n\t"
-                "s_cbranch_scc0 1f\n"
-                "0:\n\t"
-                "s_ff1_i32_b64 %[l], %[m]\n\t"
-                "s_lshl_b64 %[todo], -2, %[l]\n\t"
-                "s_bitset1_b64 %[fl], %[l]\n\t"
-                "s_nop 1\n\t"                                  // SALU-written lane select: 4 wait states
-                "v_readlane_b32 %[d], %[delta], %[l]\n\t"
-                "v_add_u32 %[q], %[q], %[d]\n\t"
-                "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
-                "s_and_b64 %[m], vcc, %[todo]\n\t"
-                "s_cbranch_scc1 0b\n"
-                "1:\n\t"
-                : [q] "+v"(q), [todo] "+s"(todo), [fl] "+s"(flipped), [m] "=&s"(m), [l] "=&s"(l_s), [d] "=&s"(d_s)
-                : [w] "v"(width), [delta] "v"(delta)
-                : "vcc", "scc");
-#else
             // The lanes above the last flipped one are selected by EXEC itself (v_cmp leaves the bits of inactive
             // lanes clear), and the +-1 of a flip is read off the slot's state mask by the scalar unit: the only
             // vector -> scalar hand-over per flip is the compare result.  6 SALU + 2 VALU, no lane-select hazard.
@@ -258,7 +231,6 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
                 : [w] "v"(width), [xm] "s"(xm_t)
                 : "vcc", "scc");
             (void)todo;
-#endif
             S += __popcll(flipped & ~xm_t) - __popcll(flipped & xm_t);
         } else {
             const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
