@@ -89,3 +89,27 @@ def test_config1_on_the_gpu():
     h, J, off = so.qubo_to_ising_dense(m.dense_Qs())
     _, en_ising, _ = so.sa_ising_neal_dense(h, J, 64, betas, seed=7, threads=8)
     assert ss.first.energy <= (en_ising + off).min() + 1e-3 * abs(ss.first.energy)   # both find the balanced cut
+
+
+def test_integration_md_ctypes_example_runs_as_written():
+    """The ctypes binding printed in INTEGRATION.md section 2, extracted from the file and executed."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes as C, numpy as np\n(.*?)```", text, re.S).group(0)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                                     # the example opens the library by its repo-relative path
+    try:
+        exec(compile(block[len("```python\n"):-3], "INTEGRATION.md", "exec"), ns)
+        rs = np.random.RandomState(0)
+        n = 96
+        A = rs.normal(size=(n, n)).astype(np.float32)
+        Qs = ((A + A.T) / 2).astype(np.float32)
+        states, energies = ns["anneal_dense"](Qs, 32, np.geomspace(0.05, 5.0, 200), 7)
+    finally:
+        os.chdir(cwd)
+    X = states.astype(np.float64)
+    assert states.shape == (32, n)
+    assert np.allclose(energies, np.einsum("ri,ij,rj->r", X, Qs.astype(np.float64), X), rtol=1e-9, atol=1e-6)
