@@ -9,7 +9,7 @@ from scrna_seq_qannealing_clustering_amd.engine import Problem
 from scrna_seq_qannealing_clustering_amd.sampler import default_potts_beta_range
 m, Qs, betas, _, graph = bench.build_workload()
 pm = models.build_dqm_potts(graph, 8, 0.005)
-R, S, n = 4096, 200, 2638
+R, S, n = int(os.environ.get("K3_R", "4096")), 200, 2638
 b = models.make_beta_schedule(S, default_potts_beta_range(pm))
 for order in ("slots", None):
     with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(np.float32), float(np.float32(pm.c_pair)), n, 8,
