@@ -23,6 +23,7 @@ class Problem:
         self.num_cases = num_cases
         self.device = device
         self._last = None
+        self._inv = None
         self.perm = perm                 # device variable j is the caller's variable perm[j] (None: identity)
 
     # -- constructors ---------------------------------------------------------------------------
@@ -175,7 +176,7 @@ class Problem:
                 raise ValueError("initial_states must have shape (num_reads, n) = (%d, %d)"
                                  % (num_reads, self.n))
             if self.perm is not None:
-                init = np.ascontiguousarray(init[:, self.perm])
+                init = np.take(init, self.perm, axis=1)
         _lib.check(_lib.load().mi_sa_anneal_ex(
             self._h, int(num_reads), C.c_uint32(int(replica_offset) & 0xFFFFFFFF), sweeps,
             _ptr(betas, C.c_double), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
@@ -210,9 +211,10 @@ class Problem:
         info = {"proposals": int(R) * int(self._last[1]) * int(self.n),
                 "accepted": int(stats[1]), "row_bytes": int(stats[2])}
         if st is not None and self.perm is not None:
-            out = np.empty_like(st)
-            out[:, self.perm] = st
-            st = out
+            # caller's variable i sits in device column inv[i]: a column gather (np.take is the fast form)
+            if self._inv is None:
+                self._inv = np.argsort(self.perm)
+            st = np.take(st, self._inv, axis=1)
         return st, en, info
 
     def best(self, want_state: bool = True):
