@@ -172,6 +172,19 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
         out["potts_dqm_k8"] = {"kernel": "k_anneal_potts<16>", "replicas": R, "sweeps": S, "kernel_ms": ms,
                                "updates_per_s": R * S * n / (ms * 1e-3), "best_energy": float(en.min()),
                                "acceptance": info["accepted"] / info["proposals"]}
+    # K4: the replica-batched energy x^T Q x of the headline's final states on the matrix cores (the one
+    # GEMM-shaped step of the path: 2 n^2 flop per state), checked against the exact fp64 path
+    from scrna_seq_qannealing_clustering_amd.engine import energy_dense
+    X = st.astype(np.uint8)
+    energy_dense(Qs, X[:64], device=rank_device, path=2)                           # warm
+    e_mfma, ms = energy_dense(Qs, X, device=rank_device, path=2, return_ms=True)
+    e_exact = energy_dense(Qs, X[:256], device=rank_device, path=1)
+    flops = 2.0 * n * n * len(X)
+    out["energy_mfma"] = {"kernel": "k_energy_dense_mfma", "states": int(len(X)), "kernel_ms": ms,
+                          "tflops": flops / (ms * 1e-3) / 1e12, "peak_tflops_f32_input_mfma": 157.3,
+                          "frac_of_mfma_peak": flops / (ms * 1e-3) / 157.3e12,
+                          "max_rel_diff_vs_exact_fp64": float(np.max(np.abs(e_mfma[:256] - e_exact) /
+                                                                     np.maximum(1.0, np.abs(e_exact))))}
     return out
 
 
