@@ -78,14 +78,18 @@ constexpr int kGemmTile = 128, kGemmKC = 32;
 
 __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restrict__ Qs, int n,
                                                            const uint8_t *__restrict__ Xt, int R, int Rpad,
-                                                           int row_tiles, double *__restrict__ out)
+                                                           int row_tiles, int ksplit, double *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) float As[2][kGemmKC][kGemmTile];
     __shared__ __attribute__((aligned(16))) float Bs[2][kGemmKC][kGemmTile];
     __shared__ unsigned int Xs[kGemmTile][kGemmTile / 32];        // X[i][r] of this tile as bits (the reduction mask)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = (blockIdx.x % row_tiles) * kGemmTile;
-    const int r0 = (blockIdx.x / row_tiles) * kGemmTile;
+    // work unit = (tile, k range): E_r is linear in Y, so a tile's k dimension may be cut into `ksplit` pieces
+    // that add their partial sums independently -- chosen by the host so that the units fill whole rounds of
+    // the chip's 2-per-CU resident workgroups (a 21 x 32 tile grid alone leaves a third of the second round idle)
+    const int ks = blockIdx.x % ksplit, tile = blockIdx.x / ksplit;
+    const int i0 = (tile % row_tiles) * kGemmTile;
+    const int r0 = (tile / row_tiles) * kGemmTile;
     const int wi = (wave & 1) * 64, wr = (wave >> 1) * 64;       // this wave's 64 x 64 corner inside the tile
     const int half = lane >> 5, col = lane & 31;
 
@@ -148,12 +152,13 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
     double e_lo = 0.0, e_hi = 0.0;                               // states wr + col and wr + 32 + col
 
-    const int chunks = (n + kGemmKC - 1) / kGemmKC;
-    load_chunk(0);
+    const int all_chunks = (n + kGemmKC - 1) / kGemmKC;
+    const int c_begin = (int)((long long)all_chunks * ks / ksplit), chunks = (int)((long long)all_chunks * (ks + 1) / ksplit);
+    load_chunk(c_begin);
     store_chunk(0);
     __syncthreads();
-    for (int c = 0; c < chunks; ++c) {
-        const int b = c & 1;
+    for (int c = c_begin; c < chunks; ++c) {
+        const int b = (c - c_begin) & 1;
         if (c + 1 < chunks) load_chunk(c + 1);                   // global loads in flight during the MFMAs below
 #pragma unroll
         for (int k0 = 0; k0 < kGemmKC; k0 += 2) {
@@ -209,8 +214,22 @@ int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, dou
         const int row_tiles = (n + kGemmTile - 1) / kGemmTile;
         hipLaunchKernelGGL(k_transpose_states, dim3(Rpad / 64, (n + 63) / 64), dim3(256), 0, st, dX, R, n, dXt, Rpad);
         hipLaunchKernelGGL(k_fill_f64, dim3((R + 255) / 256), dim3(256), 0, st, dE, R, offset);
-        hipLaunchKernelGGL(k_energy_dense_mfma, dim3(row_tiles * (Rpad / kGemmTile)), dim3(256), 0, st, dQ, n, dXt, R, Rpad,
-                           row_tiles, dE);
+        // split the k dimension so that the work units fill whole rounds of the resident workgroups
+        // (66 KB of LDS each: two per CU)
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const long long tiles = (long long)row_tiles * (Rpad / kGemmTile), resident = 2LL * (cus > 0 ? cus : 256);
+        const int all_chunks = (n + kGemmKC - 1) / kGemmKC;
+        int ksplit = 1;
+        double best = 0.0;
+        for (int k = 1; k <= 4 && k * 8 <= all_chunks; ++k) {
+            const long long units = tiles * k, rounds = (units + resident - 1) / resident;
+            const double fill = (double)units / (double)(rounds * resident);
+            if (fill > best + 0.02) { best = fill; ksplit = k; }
+        }
+        hipLaunchKernelGGL(k_energy_dense_mfma, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, st, dQ, n, dXt, R, Rpad,
+                           row_tiles, ksplit, dE);
     } else {
         hipLaunchKernelGGL(k_energy_dense_valu, dim3((R + 3) / 4), dim3(256), 0, st, dQ, n, dX, R, offset, dE);
     }
