@@ -380,10 +380,11 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
     cnt[lane] = cntv;
 
     constexpr bool PF = (D == 16);
-    struct SlotAdj { uint32_t col[D]; float val[D]; };
+    struct SlotAdj { uint32_t col[D]; float val[D]; uint32_t meta; };
     auto fetch_adj = [&](int t) {
         SlotAdj p;
         const int tt = t < slots ? t : slots - 1;
+        p.meta = a.meta[tt * 64 + lane];                     // in-slot neighbour count of this lane's variable
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             p.col[k] = a.ell_col[((size_t)tt * D + k) * 64 + lane];
@@ -417,13 +418,19 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             const uint32_t w0c = c == 0 ? w0[0] : (c == 1 ? w0[1] : (c == 2 ? w0[2] : w0[3]));
             const uint32_t w2c = c == 0 ? w2[0] : (c == 1 ? w2[1] : (c == 2 ? w2[2] : w2[3]));
             const int i = t * 64 + lane;
-            // the mover's in-slot neighbours (lane ids): issued before the prefetch (loads return in order)
-            const uint32_t metav = a.meta[i];
-            const uint4 e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D);
-            const uint4 e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D + 2);
-            asm volatile("" ::: "memory");
             SlotAdj cur;
-            if constexpr (PF) { cur = nxt; nxt = fetch_adj(t + 1); } else { cur = fetch_adj(t); }
+            if constexpr (PF) cur = nxt; else cur = fetch_adj(t);
+            const uint32_t metav = cur.meta;                 // (prefetched with the adjacency)
+            const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
+            // the movers' in-slot neighbours (lane ids) are needed only in slots that have any -- none under the
+            // slot-independent order; issued before the next slot's prefetch (loads return in order)
+            uint4 e01 = make_uint4(0u, 0u, 0u, 0u), e23 = e01;
+            if (has_in != 0ull) {
+                e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D);
+                e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D + 2);
+                asm volatile("" ::: "memory");
+            }
+            if constexpr (PF) nxt = fetch_adj(t + 1);
             K2_TICK(t_init);
             float thr = neglog_u(w0c) * T;
             if (i >= n) thr = -INFINITY;
@@ -451,9 +458,8 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             // AND + bit-count on the vector unit alone, no compare results travelling through SGPRs
             const uint32_t oa = 1u << (la & 31), ob = 1u << (lb & 31);
             const bool onehot = K <= 32;                     // wave-uniform
-            const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
             uint64_t todo = ~0ull, flipped = 0ull;
-            asm volatile("" ::"v"(metav), "v"(e01.x), "v"(e01.z), "v"(e23.x), "v"(e23.z));
+            if (has_in != 0ull) asm volatile("" ::"v"(e01.x), "v"(e01.z), "v"(e23.x), "v"(e23.z));
             auto commit_loop = [&](auto use_min_c, auto onehot_c) {
             constexpr bool UM = decltype(use_min_c)::value, OH = decltype(onehot_c)::value;
             float hd = hb - ha;
