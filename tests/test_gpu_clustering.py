@@ -128,3 +128,27 @@ def test_main_py_shaped_entry_writes_labelled_graphs(tmp_path, capsys):
     kept = [v for v in P.nodes if P.nodes[v]["label1"] == 1]
     assert len(kept) == recs["subsampling_2"]["kept"] > 0
     assert not any(P.has_edge(u, v) for i, u in enumerate(kept) for v in kept[i + 1:])   # an independent set
+
+
+def test_main_py_shaped_entry_all_methods(tmp_path, capsys):
+    """Every method block of main.py:127-161 in one run, on the three-component blobs graph."""
+    import json
+    import networkx as nx
+    from scrna_seq_qannealing_clustering_amd import outputs, run
+    fx = load_fixture("blobs")
+    src = tmp_path / "in.gexf"
+    nx.write_gexf(fx.graph(), src)
+    random.seed(5)
+    rc = run.main(["--graph", str(src), "--out", str(tmp_path), "--method", "all", "--terminate-on", "once",
+                   "--num-reads", "64", "--num-sweeps", "400", "--seed", "7"])
+    assert rc == 0
+    recs = [json.loads(line) for line in capsys.readouterr().out.strip().splitlines()]
+    assert [r["method"] for r in recs] == list(run.METHODS)
+    by = {r["method"]: r for r in recs}
+    assert by["bqm"]["components"] == [86, 85, 85]
+    assert sum(by["dqm"]["sizes"]) == 256 and sum(by["cqm"]["sizes"]) == 256
+    assert min(by["cqm"]["sizes"]) >= 20 and len(by["cqm"]["sizes"]) == 3            # the CQM's size constraint
+    assert sum(by["cqm_2"]["sizes"]) == 86 and min(by["cqm_2"]["sizes"]) >= 20      # largest component only
+    dirs = outputs.define_dirs(256, 5, 15, 15, 0.005, 0.05, "", 1, root=str(tmp_path))
+    for key in ("graph_out_bqm", "graph_out_dqm", "graph_out_cqm", "graph_out_pru1", "graph_out_pru2"):
+        assert nx.read_gexf(dirs[key]).number_of_nodes() > 0, key
