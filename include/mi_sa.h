@@ -156,6 +156,10 @@ int mi_sa_qubo_dense_f32(const float *Qs, int n, double offset, int R, int num_s
  * into fp64: ~1e-7 of sum|terms|).  out_kernel_ms (nullable): device time of the evaluation kernels. */
 int mi_energy_dense_f32(const float *Qs, int n, const uint8_t *X, int R, double offset,
                         double *out_energy, int device);
+/* The same evaluation over an fp64 matrix (the caller's own coefficients, every entry added once into fp64):
+ * the energies dimod's SampleSet.from_samples_bqm computes on the host for the samples of a dense model. */
+int mi_energy_dense_f64(const double *Qs, int n, const uint8_t *X, int R, double offset,
+                        double *out_energy, int device);
 int mi_energy_dense_f32_ex(const float *Qs, int n, const uint8_t *X, int R, double offset,
                            double *out_energy, int device, int path, float *out_kernel_ms);
 

@@ -19,7 +19,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ void __launch_bounds__(256) k_energy_dense_valu(const float *__restrict__ Qs, int n,
+template <typename QT>
+__global__ void __launch_bounds__(256) k_energy_dense_valu(const QT *__restrict__ Qs, int n,
                                                            const uint8_t *__restrict__ X, int R,
                                                            double offset, double *__restrict__ out)
 {
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(256) k_energy_dense_valu(const float *__restri
     double e = 0.0;
     for (int i = 0; i < n; ++i) {
         if (!x[i]) continue;                    // wave-uniform (same address for all lanes)
-        const float *row = Qs + (size_t)i * n;
+        const QT *row = Qs + (size_t)i * n;
         for (int j = lane; j < n; j += 64)
             if (x[j]) e += (double)row[j];
     }
@@ -231,8 +232,16 @@ int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, dou
         hipLaunchKernelGGL(k_energy_dense_mfma, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, st, dQ, n, dXt, R, Rpad,
                            row_tiles, ksplit, dE);
     } else {
-        hipLaunchKernelGGL(k_energy_dense_valu, dim3((R + 3) / 4), dim3(256), 0, st, dQ, n, dX, R, offset, dE);
+        hipLaunchKernelGGL(k_energy_dense_valu<float>, dim3((R + 3) / 4), dim3(256), 0, st, dQ, n, dX, R, offset, dE);
     }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// the same sum over an fp64 matrix (the caller's own coefficients): one wavefront per state
+int mi_launch_energy_dense_f64(const double *dQ, int n, const uint8_t *dX, int R, double offset, double *dE, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_energy_dense_valu<double>, dim3((R + 3) / 4), dim3(256), 0, st, dQ, n, dX, R, offset, dE);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }

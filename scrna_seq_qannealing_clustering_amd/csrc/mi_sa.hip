@@ -752,6 +752,31 @@ int mi_energy_dense_f32_ex(const float *Qs, int n, const uint8_t *X, int R, doub
     return rc;
 }
 
+int mi_energy_dense_f64(const double *Qs, int n, const uint8_t *X, int R, double offset,
+                        double *out_energy, int device)
+{
+    if (!Qs || !X || !out_energy) return fail(MI_EINVAL, "NULL argument");
+    if (n < 1 || R < 1) return fail(MI_EINVAL, "n and R must be >= 1");
+    int rc = select_device(device);
+    if (rc) return rc;
+    double *dQ = nullptr, *dE = nullptr; uint8_t *dX = nullptr;
+    rc = [&]() -> int {
+        HIP_TRY(hipMalloc((void **)&dQ, (size_t)n * n * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&dX, (size_t)R * n));
+        HIP_TRY(hipMalloc((void **)&dE, (size_t)R * sizeof(double)));
+        HIP_TRY(hipMemcpy(dQ, Qs, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dX, X, (size_t)R * n, hipMemcpyHostToDevice));
+        int r2 = mi_launch_energy_dense_f64(dQ, n, dX, R, offset, dE, 0);
+        if (r2) return r2;
+        HIP_TRY(hipMemcpy(out_energy, dE, (size_t)R * sizeof(double), hipMemcpyDeviceToHost));
+        return MI_OK;
+    }();
+    if (dQ) (void)hipFree(dQ);
+    if (dX) (void)hipFree(dX);
+    if (dE) (void)hipFree(dE);
+    return rc;
+}
+
 int mi_energy_dense_f32(const float *Qs, int n, const uint8_t *X, int R, double offset,
                         double *out_energy, int device)
 {

@@ -268,6 +268,7 @@ __device__ __forceinline__ uint32_t chain_word_dev(uint32_t i, uint32_t s, uint3
 // K4 launcher (energy_kernels.hip); all pointers are device pointers
 int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, double offset, double *dE,
                            uint8_t *dXt, int path, hipStream_t st);
+int mi_launch_energy_dense_f64(const double *dQ, int n, const uint8_t *dX, int R, double offset, double *dE, hipStream_t st);
 
 // Energy of the final state, E = sum_i x_i diag_i + 1/2 sum_{i,j} x_i x_j Q2_ij, with every fp32 matrix
 // entry added EXACTLY once into fp64 accumulators (lane l sums its own columns over all set rows; one

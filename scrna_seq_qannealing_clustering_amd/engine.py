@@ -246,3 +246,16 @@ def energy_dense(Qs: np.ndarray, X: np.ndarray, offset: float = 0.0, device: int
                                                   X.shape[0], float(offset), _ptr(out, C.c_double),
                                                   int(device), int(path), C.byref(ms)))
     return (out, float(ms.value)) if return_ms else out
+
+
+def energy_dense_f64(Qs: np.ndarray, X: np.ndarray, offset: float = 0.0, device: int = 0) -> np.ndarray:
+    """``E_r = x_r^T Qs x_r + offset`` over an fp64 matrix on the GPU (every entry added once into fp64): the
+    caller-model energies of a dense problem's samples."""
+    Qs = np.ascontiguousarray(Qs, dtype=np.float64)
+    X = np.ascontiguousarray(X, dtype=np.uint8)
+    if X.ndim != 2 or Qs.ndim != 2 or Qs.shape[0] != Qs.shape[1] or X.shape[1] != Qs.shape[0]:
+        raise ValueError("Qs must be n x n and X must have shape (R, n)")
+    out = np.empty(X.shape[0], dtype=np.float64)
+    _lib.check(_lib.load().mi_energy_dense_f64(_ptr(Qs, C.c_double), Qs.shape[0], _ptr(X, C.c_uint8), X.shape[0],
+                                               float(offset), _ptr(out, C.c_double), int(device)))
+    return out

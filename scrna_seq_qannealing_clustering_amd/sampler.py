@@ -28,7 +28,7 @@ import numpy as np
 
 from . import _lib
 from .bqm import BinaryQuadraticModel, DiscreteQuadraticModel
-from .engine import Problem
+from .engine import Problem, energy_dense_f64
 from .models import (PottsModel, QuboModel, _csr_from_edges, default_beta_range,
                      make_beta_schedule, qubo_dict_to_model)
 from .sampleset import SampleSet
@@ -233,8 +233,8 @@ class MI355XSampler:
                                      offset=model.offset, device=self.device, order="slots",
                                      energy_model=(model.val, model.lin, model.c_pair))
         else:
-            prob = Problem.dense(_symmetric_f32(model.dense_Qs()), offset=model.offset,
-                                 device=self.device)
+            dense64 = model.dense_Qs()
+            prob = Problem.dense(_symmetric_f32(dense64), offset=model.offset, device=self.device)
         with prob:
             init_arr = init
             if isinstance(init, tuple):           # partial initial states + random remainder
@@ -251,8 +251,8 @@ class MI355XSampler:
             t2 = time.perf_counter()
         # energies in the caller's fp64 coefficients (what dimod's SampleSet.from_samples_bqm evaluates on the
         # host): the structured kernel evaluates them itself (energy_model above); the dense kernels report
-        # the energies of the fp32 matrix they anneal, so that path re-evaluates here
-        energies = dev_energy if use_csr else model.energies(states)
+        # the energies of the fp32 matrix they anneal, so that path runs the fp64 energy kernel on the samples
+        energies = dev_energy if use_csr else energy_dense_f64(dense64, states, model.offset, self.device)
         samples = states.astype(np.int8)
         if vartype == "SPIN":
             samples = 2 * samples - 1
@@ -263,7 +263,7 @@ class MI355XSampler:
             "timing": {"upload_s": t1 - t0, "anneal_s": t2 - t1, "kernel_ms": kernel_ms},
             "updates_per_s": (stats["proposals"] / (kernel_ms * 1e-3)) if kernel_ms > 0 else None,
             "accepted": stats["accepted"], "proposals": stats["proposals"],
-            "energy_evaluation": "device fp64 (caller's coefficients)" if use_csr else "host fp64",
+            "energy_evaluation": "device fp64 (caller's coefficients)",
             "device_energy_max_abs_diff": float(np.max(np.abs(dev_energy - energies))),
             "ignored_kwargs": ignored,
         }

@@ -315,3 +315,19 @@ def test_dense_beyond_4096_variables_workgroup_per_replica(n, R, sweeps):
         assert info["accepted"] == int(ostats[1]) and info["accepted"] > n // 10
         assert np.array_equal(st, ost)
         assert np.allclose(en, oen, rtol=1e-5, atol=1e-3)
+
+
+def test_energy_kernel_fp64_matrix():
+    """mi_energy_dense_f64: the caller-model energies of a dense problem's samples, against numpy fp64."""
+    from scrna_seq_qannealing_clustering_amd.engine import energy_dense_f64
+    rs = np.random.RandomState(9)
+    for n, R in ((1, 1), (65, 3), (300, 70), (1030, 9)):
+        A = rs.normal(size=(n, n))
+        Qs = (A + A.T) / 2
+        X = (rs.rand(R, n) < 0.4).astype(np.uint8)
+        got = energy_dense_f64(Qs, X, offset=1.25)
+        Xf = X.astype(np.float64)
+        want = np.einsum("ri,ij,rj->r", Xf, Qs, Xf) + 1.25
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+    with pytest.raises(ValueError):
+        energy_dense_f64(np.zeros((3, 4)), np.zeros((1, 3), dtype=np.uint8))
