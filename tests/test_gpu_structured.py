@@ -503,3 +503,69 @@ def test_full_size_properties_config5_kidney_k15():
     back = slice(None) if perm is None else np.argsort(perm)
     olab, _, _ = so.potts_csr_philox(rp2, c2, v2, c_pair, n, K, 1, np.full(5, betas[77]), 31, replica_offset=77)
     assert np.array_equal(lab[77:78], olab[:, back])
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_structured_kernels_random_models(seed):
+    """Random sparse models (size, degree, weights, K, schedule, order, replica offset drawn per seed) through K2
+    and K3 against the oracle: states / labels, accepted counts and energies."""
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.choice([3, 17, 63, 64, 65, 130, 257, 700]))
+    max_deg = int(rs.choice([1, 3, 9, 16, 17, 33, 60]))
+    m = min(n * max_deg // 3, n * (n - 1) // 2)
+    pairs = set()
+    deg = np.zeros(n, dtype=int)
+    for _ in range(4 * m):
+        if len(pairs) >= m:
+            break
+        a, b = (int(x) for x in rs.randint(0, n, 2))
+        if a == b or (min(a, b), max(a, b)) in pairs or deg[a] >= max_deg or deg[b] >= max_deg:
+            continue
+        pairs.add((min(a, b), max(a, b)))
+        deg[a] += 1
+        deg[b] += 1
+    edges = sorted(pairs)
+    w = rs.choice(np.array([1 / 9, 0.25, 3 / 7, 2 / 3, 1.0, -0.5]), size=len(edges)).astype(np.float32)
+    rowptr, col, val = _csr_from_edges(n, edges, w)
+    lin = rs.normal(scale=0.7, size=n).astype(np.float32)
+    c_pair = float(np.float32(rs.choice([0.0, 0.03, 0.4, -0.02])))
+    sweeps = int(rs.choice([1, 4, 13]))
+    betas = np.geomspace(float(rs.choice([0.05, 0.5])), float(rs.choice([2.0, 40.0])), sweeps)
+    R = int(rs.choice([1, 2, 7]))
+    off = int(rs.choice([0, 5, 2 ** 31 - 3]))
+    order = [None, "slots"][seed & 1]
+    with Problem.csr_rank1(rowptr, col, val, lin, c_pair, order=order) as p:
+        p.anneal(R, betas, 7 + seed, replica_offset=off)
+        st, en, info = p.fetch()
+        perm = p.perm
+    if perm is None:
+        o_args, back = (rowptr, col, val, lin, c_pair), slice(None)
+    else:
+        rp2, c2, v2 = models.permute_csr(rowptr, col, val, perm)
+        o_args, back = (rp2, c2, v2, lin[perm], c_pair), np.argsort(perm)
+    ost, oen, ostats = so.sa_csr_rank1_philox(*o_args, R, betas, 7 + seed, replica_offset=off)
+    assert np.array_equal(st, ost[:, back]) and info["accepted"] == int(ostats[1])
+    assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+
+    K = int(rs.choice([2, 3, 8, 15, 16, 17, 32, 33, 64]))
+    min_size = int(rs.choice([0, 0, 1, 2])) if n >= 4 * K else 0
+    init = None
+    if min_size:
+        init = (np.arange(n)[None, :] % K).repeat(R, axis=0).astype(np.uint16)       # every cluster >= n // K members
+    with Problem.potts_csr(rowptr, col, val, c_pair, n, K, order=order) as p:
+        if min_size:
+            p.set_option("min_cluster_size", min_size)
+        p.anneal(R, betas, 70 + seed, replica_offset=off, initial_states=init)
+        lab, en, info = p.fetch()
+        perm = p.perm
+    if perm is None:
+        o_args, back, oinit = (rowptr, col, val, c_pair, n, K), slice(None), init
+    else:
+        rp2, c2, v2 = models.permute_csr(rowptr, col, val, perm)
+        o_args, back, oinit = (rp2, c2, v2, c_pair, n, K), np.argsort(perm), (None if init is None else init[:, perm])
+    olab, oen, ostats = so.potts_csr_philox(*o_args, R, betas, 70 + seed, replica_offset=off, init=oinit,
+                                            min_size=min_size)
+    assert np.array_equal(lab, olab[:, back]) and info["accepted"] == int(ostats[1])
+    assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
+    if min_size:
+        assert all(np.bincount(row, minlength=K).min() >= min_size for row in lab)
