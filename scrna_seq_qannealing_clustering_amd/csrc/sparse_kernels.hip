@@ -511,9 +511,10 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                 const float hd = hb - ha;
                 if (K <= 16) {
                     // the mover's clusters travel as 2 x their ids; W holds a signed 2-bit field per cluster
-                    // (+1 at the target, -1 at the source), so a lane's size change is one v_bfe_i32 per label:
-                    // 9 VALU + 8 SALU per move
+                    // (+1 at the target, -1 at the source) and W' the negated fields, so a lane's change is one
+                    // v_bfe_i32 per label and one three-operand add: 8 VALU + 11 SALU per move
                     const int la2 = la * 2, lb2 = lb * 2;
+                    uint32_t w1_s, w2_s;
                     asm volatile(
                         "0:\n\t"
                         "v_cvt_f32_i32 %[t0], %[id]\n\t"
@@ -527,19 +528,21 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                         "v_readlane_b32 %[sa], %[la2], %[l]\n\t"
                         "v_readlane_b32 %[sb], %[lb2], %[l]\n\t"
                         "s_nop 0\n\t"
-                        "s_lshl_b32 %[sa], 3, %[sa]\n\t"        // -1 at the source cluster
-                        "s_lshl_b32 %[sb], 1, %[sb]\n\t"        // +1 at the target cluster
+                        "s_lshl_b32 %[w1], 3, %[sa]\n\t"        // W : -1 at the source cluster,
+                        "s_lshl_b32 %[w2], 1, %[sb]\n\t"        //     +1 at the target cluster
+                        "s_or_b32 %[w1], %[w1], %[w2]\n\t"
+                        "s_lshl_b32 %[sa], 1, %[sa]\n\t"        // W': the negated fields (for this lane's a-label)
+                        "s_lshl_b32 %[sb], 3, %[sb]\n\t"
                         "s_or_b32 %[sa], %[sa], %[sb]\n\t"
                         "s_nop 0\n\t"
-                        "v_bfe_i32 %[t0], %[sa], %[lb2], 2\n\t"
-                        "v_bfe_i32 %[t1], %[sa], %[la2], 2\n\t"
-                        "v_sub_u32 %[t0], %[t0], %[t1]\n\t"
-                        "v_add_u32 %[id], %[id], %[t0]\n\t"
+                        "v_bfe_i32 %[t0], %[w1], %[lb2], 2\n\t"  // change of n_b
+                        "v_bfe_i32 %[t1], %[sa], %[la2], 2\n\t"  // -(change of n_a)
+                        "v_add3_u32 %[id], %[id], %[t0], %[t1]\n\t"
                         "s_branch 0b\n"
                         "1:\n\t"
                         "s_mov_b64 exec, -1\n\t"
                         : [id] "+v"(idf), [fl] "+s"(flipped), [t0] "=&v"(t0), [t1] "=&v"(t1), [l] "=&s"(l_s),
-                          [sa] "=&s"(sa_s), [sb] "=&s"(sb_s)
+                          [sa] "=&s"(sa_s), [sb] "=&s"(sb_s), [w1] "=&s"(w1_s), [w2] "=&s"(w2_s)
                         : [c] "s"(a.c_pair), [hd] "v"(hd), [thr] "v"(thr), [la2] "v"(la2), [lb2] "v"(lb2)
                         : "vcc", "scc");
                 } else {
