@@ -68,7 +68,8 @@ int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col
                                        int device, mi_sa_problem **out);
 
 /* Potts / DQM model E(l) = lin_offset + sum_{u<v, l_u==l_v} (c_pair + S_uv), K cases per variable:
- * the model clustering_dqm builds (DQM_clustering.py:29-43) and hands to sample_dqm (:45). */
+ * the model clustering_dqm builds (DQM_clustering.py:29-43) and hands to sample_dqm (:45).  Rows of any
+ * width up to 4096 neighbours (up to 64 they are register resident); n <= 40000, K <= 64. */
 int mi_sa_problem_create_potts_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                                        float c_pair, int n, int K, double lin_offset, int device,
                                        mi_sa_problem **out);

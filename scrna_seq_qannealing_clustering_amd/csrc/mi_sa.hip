@@ -335,9 +335,12 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
         if (d < 0) return fail(MI_EINVAL, "rowptr is not monotone at %d", i);
         if (d > maxdeg) maxdeg = d;
     }
-    if (maxdeg > 64)
+    // the binary kernel K2 keeps a slot's adjacency in registers: rows up to 64 wide (wider models run on the
+    // dense kernels); the k-way kernel K3 has a runtime-width form that reads the adjacency from L2
+    if (maxdeg > 64 && p->kind != MI_KIND_POTTS_CSR)
         return fail(MI_EUNSUPPORTED, "max degree %d exceeds the slot-ELL width built (64); use the dense kernel", maxdeg);
-    const int D = maxdeg <= 16 ? 16 : (maxdeg <= 32 ? 32 : 64);
+    if (maxdeg > 4096) return fail(MI_EUNSUPPORTED, "max degree %d exceeds 4096", maxdeg);
+    const int D = maxdeg <= 16 ? 16 : (maxdeg <= 32 ? 32 : (maxdeg <= 64 ? 64 : ((maxdeg + 15) / 16) * 16));
     const int slots = (n + 63) / 64;
     std::vector<uint32_t> hc((size_t)slots * D * 64);
     std::vector<float> hv((size_t)slots * D * 64, 0.0f);

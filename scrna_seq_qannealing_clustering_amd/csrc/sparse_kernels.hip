@@ -341,9 +341,13 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
 // moved variable among their neighbours -- found from the mover's in-slot neighbour list (`rows` / `meta`,
 // as in K2), not by scanning every lane's row.  A mover is never tested again in its slot, so its label is
 // written after the loop -- unless it has in-slot neighbours, which read it back at once.
+// D = 16 / 32 / 64: the slot's adjacency is register resident (prefetched for D = 16).  D = 0: rows of ANY width
+// W = a.D (a multiple of 16; the untrimmed SNN graphs of the reference reach degrees of order k^2): the adjacency
+// is read entry by entry from L2 inside the field sum -- the same chain, slower.
 template <int D>
 __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs a)
 {
+    const int W = D ? D : a.D;                               // adjacency entries per variable
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -380,15 +384,19 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
     cnt[lane] = cntv;
 
     constexpr bool PF = (D == 16);
-    struct SlotAdj { uint32_t col[D]; float val[D]; uint32_t meta; };
+    constexpr int DR = D ? D : 1;                            // register-resident entries (none for D = 0)
+    struct SlotAdj { uint32_t col[DR]; float val[DR]; uint32_t meta; int slot; };
     auto fetch_adj = [&](int t) {
         SlotAdj p;
         const int tt = t < slots ? t : slots - 1;
+        p.slot = tt;
         p.meta = a.meta[tt * 64 + lane];                     // in-slot neighbour count of this lane's variable
+        if constexpr (D != 0) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            p.col[k] = a.ell_col[((size_t)tt * D + k) * 64 + lane];
-            p.val[k] = a.ell_val[((size_t)tt * D + k) * 64 + lane];
+            for (int k = 0; k < D; ++k) {
+                p.col[k] = a.ell_col[((size_t)tt * D + k) * 64 + lane];
+                p.val[k] = a.ell_val[((size_t)tt * D + k) * 64 + lane];
+            }
         }
         return p;
     };
@@ -426,8 +434,8 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             // slot-independent order; issued before the next slot's prefetch (loads return in order)
             uint4 e01 = make_uint4(0u, 0u, 0u, 0u), e23 = e01;
             if (has_in != 0ull) {
-                e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D);
-                e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D + 2);
+                e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * W);
+                e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * W + 2);
                 asm volatile("" ::: "memory");
             }
             if constexpr (PF) nxt = fetch_adj(t + 1);
@@ -443,11 +451,21 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             auto sum_h = [&]() {
                 ha = 0.0f;
                 hb = 0.0f;
+                if constexpr (D != 0) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const int lj = lab[cur.col[k]];
-                    ha = ha + ((lj == la) ? cur.val[k] : 0.0f);
-                    hb = hb + ((lj == lb) ? cur.val[k] : 0.0f);
+                    for (int k = 0; k < D; ++k) {
+                        const int lj = lab[cur.col[k]];
+                        ha = ha + ((lj == la) ? cur.val[k] : 0.0f);
+                        hb = hb + ((lj == lb) ? cur.val[k] : 0.0f);
+                    }
+                } else {
+                    for (int k = 0; k < W; ++k) {            // padding entries: (the variable itself, +0.0f)
+                        const size_t at = ((size_t)cur.slot * W + k) * 64 + lane;
+                        const int lj = lab[a.ell_col[at]];
+                        const float v = a.ell_val[at];
+                        ha = ha + ((lj == la) ? v : 0.0f);
+                        hb = hb + ((lj == lb) ? v : 0.0f);
+                    }
                 }
             };
             K2_TICK(t_pre);
@@ -492,7 +510,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                     if (nin > 1) touched |= lane == (int)(__builtin_amdgcn_readlane((int)e01.z, l) & 63);
                     if (nin > 2) touched |= lane == (int)(__builtin_amdgcn_readlane((int)e23.x, l) & 63);
                     if (nin > 3) touched |= lane == (int)(__builtin_amdgcn_readlane((int)e23.z, l) & 63);
-                    for (int k = 4; k < nin; ++k) touched |= lane == (int)(rows[((size_t)t * 64 + l) * D + k].x & 63u);
+                    for (int k = 4; k < nin; ++k) touched |= lane == (int)(rows[((size_t)t * 64 + l) * W + k].x & 63u);
                     if (touched) { sum_h(); hd = hb - ha; }
                 }
             }
@@ -607,9 +625,9 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
         if (i >= n) continue;
         const int li = lab[i];
         dst[i] = (uint16_t)li;
-        for (int k = 0; k < D; ++k) {
-            const uint32_t cc = a.ell_col[((size_t)t * D + k) * 64 + lane];
-            const size_t at = ((size_t)t * D + k) * 64 + lane;
+        for (int k = 0; k < W; ++k) {
+            const uint32_t cc = a.ell_col[((size_t)t * W + k) * 64 + lane];
+            const size_t at = ((size_t)t * W + k) * 64 + lane;
             const double vv = a.ell_val64 ? a.ell_val64[at] : (double)a.ell_val[at];
             if ((int)cc > i && lab[cc] == li) e += vv;
         }
@@ -673,6 +691,7 @@ int mi_launch_potts(const EllArgs &a, hipStream_t st)
     if (a.D == 16) return launch_sparse(k_anneal_potts<16>, a, per_wave, st);
     if (a.D == 32) return launch_sparse(k_anneal_potts<32>, a, per_wave, st);
     if (a.D == 64) return launch_sparse(k_anneal_potts<64>, a, per_wave, st);
+    if (a.D > 64 && a.D % 16 == 0) return launch_sparse(k_anneal_potts<0>, a, per_wave, st);     // rows of any width
     return fail(MI_EUNSUPPORTED, "slot-ELL width %d not built", a.D);
 }
 

@@ -113,3 +113,22 @@ def test_integration_md_ctypes_example_runs_as_written():
     X = states.astype(np.float64)
     assert states.shape == (32, n)
     assert np.allclose(energies, np.einsum("ri,ij,rj->r", X, Qs.astype(np.float64), X), rtol=1e-9, atol=1e-6)
+
+
+def test_sample_dqm_on_a_graph_with_rows_wider_than_64():
+    """clustering_dqm's model on an untrimmed-SNN-like graph (two dense communities, degree ~ 90): the k-way
+    kernel's runtime-width form behind the sampler; the two communities come out as the two clusters."""
+    import networkx as nx
+    from scrna_seq_qannealing_clustering_amd import build_dqm_potts
+    rs = np.random.RandomState(2)
+    G = nx.Graph()
+    G.add_nodes_from(str(i) for i in range(240))
+    for a in range(240):
+        for b in range(a + 1, 240):
+            same = (a < 120) == (b < 120)
+            if same and rs.rand() < 0.75:                    # no edges between the communities: splitting them wins
+                G.add_edge(str(a), str(b), weight=float(rs.choice([0.25, 3 / 7, 2 / 3, 1.0])))
+    assert max(d for _, d in G.degree()) > 64
+    ss = MI355XSampler().sample_dqm(build_dqm_potts(G, 2, 0.005), num_reads=32, num_sweeps=300, seed=3)
+    lab = np.array([ss.first.sample[str(i)] for i in range(240)])
+    assert len(set(lab[:120])) == 1 and len(set(lab[120:])) == 1 and lab[0] != lab[239]

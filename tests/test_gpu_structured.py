@@ -569,3 +569,53 @@ def test_structured_kernels_random_models(seed):
     assert np.allclose(en, oen, rtol=1e-9, atol=1e-9)
     if min_size:
         assert all(np.bincount(row, minlength=K).min() >= min_size for row in lab)
+
+
+@pytest.mark.parametrize("n,max_deg,K", [(200, 100, 3), (700, 300, 8), (130, 129, 15)])
+@pytest.mark.parametrize("order", [None, "slots"])
+def test_potts_rows_wider_than_64(n, max_deg, K, order):
+    """k-way models whose rows exceed the 64-entry register layout (the reference's UNTRIMMED SNN graphs reach
+    degrees of order k^2; (130, 129) is a complete graph): K3's runtime-width form against the oracle."""
+    rs = np.random.RandomState(n + max_deg)
+    if max_deg >= n - 1:
+        edges = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    else:
+        pairs, deg = set(), np.zeros(n, dtype=int)
+        hubs = rs.choice(n, size=5, replace=False)
+        for h in hubs:                                           # a few hubs at the cap, a sparse rest
+            for j in rs.permutation(n):
+                if deg[h] >= max_deg:
+                    break
+                j = int(j)
+                if j != h and (min(h, j), max(h, j)) not in pairs and deg[j] < max_deg:
+                    pairs.add((min(int(h), j), max(int(h), j)))
+                    deg[h] += 1
+                    deg[j] += 1
+        for _ in range(3 * n):
+            a, b = (int(x) for x in rs.randint(0, n, 2))
+            if a != b and (min(a, b), max(a, b)) not in pairs and deg[a] < max_deg and deg[b] < max_deg:
+                pairs.add((min(a, b), max(a, b)))
+                deg[a] += 1
+                deg[b] += 1
+        edges = sorted(pairs)
+    w = rs.choice(np.array([1 / 9, 0.25, 3 / 7, 2 / 3, 1.0]), size=len(edges)).astype(np.float32)
+    rowptr, col, val = _csr_from_edges(n, edges, -2.0 * w)
+    assert int(np.diff(rowptr).max()) > 64
+    betas = np.geomspace(0.05, 6.0, 9)
+    R = 4
+    with Problem.potts_csr(rowptr, col, val, 0.01, n, K, order=order, energy_model=(val.astype(np.float64), 0.01)) as p:
+        p.anneal(R, betas, 17, replica_offset=3)
+        lab, en, info = p.fetch()
+        perm = p.perm
+    if perm is None:
+        o_args, back = (rowptr, col, val, 0.01, n, K), slice(None)
+    else:
+        rp2, c2, v2 = models.permute_csr(rowptr, col, val, perm)
+        o_args, back = (rp2, c2, v2, 0.01, n, K), np.argsort(perm)
+    olab, oen, ostats = so.potts_csr_philox(*o_args, R, betas, 17, replica_offset=3)
+    assert np.array_equal(lab, olab[:, back]) and info["accepted"] == int(ostats[1]) > 0
+    assert np.allclose(en, _potts_host_energy(rowptr, col, val.astype(np.float64), 0.01, 0.0, lab.astype(np.int64), K),
+                       rtol=1e-12, atol=1e-9)
+    # the binary kernel keeps its 64-entry limit (the sampler routes such models to the dense kernels)
+    with pytest.raises(_lib.MiSaError):
+        Problem.csr_rank1(rowptr, col, val, np.zeros(n, dtype=np.float32), 0.0)
