@@ -62,7 +62,8 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
 
 /* Structured binary model E(x) = sum lin_i x_i + sum_{i<j} (c_pair + S_ij) x_i x_j + offset,
  * S symmetric sparse in CSR (both directions stored).  This is exactly the shape of the reference's
- * graph-partition QUBO (BQM_clustering.py:38-47: sparse cut term + 2*gamma on every pair). */
+ * graph-partition QUBO (BQM_clustering.py:38-47: sparse cut term + 2*gamma on every pair).  Rows of up to 4096
+ * neighbours (up to 64 they are register resident); n <= 2^20. */
 int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                                        const float *lin, float c_pair, int n, double offset,
                                        int device, mi_sa_problem **out);

@@ -8,7 +8,7 @@ from scrna_seq_qannealing_clustering_amd.engine import Problem
 from scrna_seq_qannealing_clustering_amd.sampler import default_potts_beta_range
 
 R, S, n = 4096, 200, 2638
-for k, ord_ in ((5, 15), (8, 30), (12, 60)):
+for k, ord_ in ((5, 15), (8, 30), (12, 60), (20, 120)):
     nodes, eu, ev, w, _ = graphs.synthetic_snn(n, k, 15, ord_, 9, seed=0)
     G = graphs.EdgeListGraph(nodes, eu, ev, w)
     m = models.build_bqm_qubo(G, 0.05)

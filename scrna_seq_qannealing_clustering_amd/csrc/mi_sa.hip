@@ -335,11 +335,10 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
         if (d < 0) return fail(MI_EINVAL, "rowptr is not monotone at %d", i);
         if (d > maxdeg) maxdeg = d;
     }
-    // the binary kernel K2 keeps a slot's adjacency in registers: rows up to 64 wide (wider models run on the
-    // dense kernels); the k-way kernel K3 has a runtime-width form that reads the adjacency from L2
-    if (maxdeg > 64 && p->kind != MI_KIND_POTTS_CSR)
-        return fail(MI_EUNSUPPORTED, "max degree %d exceeds the slot-ELL width built (64); use the dense kernel", maxdeg);
-    if (maxdeg > 4096) return fail(MI_EUNSUPPORTED, "max degree %d exceeds 4096", maxdeg);
+    // rows up to 64 wide are register resident in K2 and K3; wider ones (any multiple of 16 up to 4096) run on the
+    // runtime-width forms of the same kernels, which read the adjacency from L2 inside the field sum
+    if (maxdeg > 4096)
+        return fail(MI_EUNSUPPORTED, "max degree %d exceeds the widest adjacency layout (4096); use the dense kernel", maxdeg);
     const int D = maxdeg <= 16 ? 16 : (maxdeg <= 32 ? 32 : (maxdeg <= 64 ? 64 : ((maxdeg + 15) / 16) * 16));
     const int slots = (n + 63) / 64;
     std::vector<uint32_t> hc((size_t)slots * D * 64);

@@ -98,22 +98,28 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
     // buffers (the slot loop is unrolled by two, so no copies) with D/2 buffer_load_dwordx4 whose addresses
     // cost no VALU work: descriptor + (lane*16) + scalar slot offset + immediate.
     //   adj4 layout per slot: for g < D/4: [64 lanes][4] packed neighbours, then [64 lanes][4] values.
-    constexpr int G = D / 4;
+    // D = 16 / 32 / 64: register resident.  D = 0: rows of any width W = a.D (a multiple of 16): the adjacency is
+    // read group by group inside the field sum (no prefetch) -- the same chain for the untrimmed graphs' wide rows.
+    constexpr int G = D ? D / 4 : 1;
+    const int W = D ? D : a.D, Gw = W / 4;
     const __amdgpu_buffer_rsrc_t rs_adj = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(a.adj4), 0, slots * G * 2048, 0x00020000);
+        const_cast<uint4 *>(a.adj4), 0, slots * Gw * 2048, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_lin = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.lin), 0, slots * 256, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_flag = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(a.slot_flags), 0, slots * 4, 0x00020000);
-    struct SlotAdj { u32x4 col[G]; u32x4 val[G]; uint32_t lin, flag; };
+    struct SlotAdj { u32x4 col[G]; u32x4 val[G]; uint32_t lin, flag; int soff; };
     auto fetch_adj = [&](int t) {
         SlotAdj p;
         const int tt = t < slots ? t : slots - 1;
-        const int soff = tt * (G * 2048);
+        const int soff = tt * (Gw * 2048);
+        p.soff = soff;
+        if constexpr (D != 0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            p.col[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16, soff + g * 2048, 0);
-            p.val[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16, soff + g * 2048 + 1024, 0);
+            for (int g = 0; g < G; ++g) {
+                p.col[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16, soff + g * 2048, 0);
+                p.val[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16, soff + g * 2048 + 1024, 0);
+            }
         }
         p.lin = __builtin_amdgcn_raw_buffer_load_b32(rs_lin, lane * 4, tt * 256, 0);
         p.flag = __builtin_amdgcn_raw_buffer_load_b32(rs_flag, 0, tt * 4, 0);   // arrives with the prefetch: no stall
@@ -139,34 +145,48 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         uint4 e01 = make_uint4(0u, 0u, 0u, 0u), e23 = e01;
         if (general) {
             metav = a.meta[i];
-            e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D);
-            e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * D + 2);
+            e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * W);
+            e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * W + 2);
         }
         K2_TICK(t_init);
         // fresh field: lin_i + the stored neighbours whose bit is set, in stored order.  A clear bit adds +0.0f
         // (value AND mask): x + 0.0f == x for every x except -0.0f, and +-0.0f are the same number to every
         // comparison downstream -- no decision can differ from the oracle's skip.
         float gi = __uint_as_float(cur.lin);
-#pragma unroll
-        for (int g0 = 0; g0 < G; g0 += 4) {                   // 16 state words in flight, then 16 adds
+        auto add16 = [&](const u32x4 *c4, const u32x4 *v4) {  // 16 state words in flight, then 16 adds
             uint32_t word[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const uint32_t pk = cur.col[g0 + k / 4][k & 3];
+                const uint32_t pk = c4[k / 4][k & 3];
                 if constexpr (XB) word[k] = (uint32_t)(unsigned char)lds[pk];           // packed word = the index
                 else word[k] = *reinterpret_cast<const uint32_t *>(lds + (pk >> 8));
             }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const uint32_t pk = cur.col[g0 + k / 4][k & 3];
+                const uint32_t pk = c4[k / 4][k & 3];
                 if constexpr (XB) {
                     // fma(val, 1, g) = g + val and fma(val, 0, g) = g: the oracle's conditional add, one rounding
-                    gi = __fmaf_rn(__uint_as_float(cur.val[g0 + k / 4][k & 3]), (float)word[k], gi);
+                    gi = __fmaf_rn(__uint_as_float(v4[k / 4][k & 3]), (float)word[k], gi);
                 } else {
                     const int msk = __builtin_amdgcn_sbfe((int)word[k], pk, 1u);   // v_bfe_i32: bit pk[4:0] -> 0 / -1
-                    gi = gi + __uint_as_float(cur.val[g0 + k / 4][k & 3] & (uint32_t)msk);
+                    gi = gi + __uint_as_float(v4[k / 4][k & 3] & (uint32_t)msk);
                 }
+            }
+        };
+        if constexpr (D != 0) {
+#pragma unroll
+            for (int g0 = 0; g0 < G; g0 += 4) add16(&cur.col[g0], &cur.val[g0]);
+        } else {
+#pragma unroll 1
+            for (int g0 = 0; g0 < Gw; g0 += 4) {
+                u32x4 c4[4], v4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    c4[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16, cur.soff + (g0 + q) * 2048, 0);
+                    v4[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16, cur.soff + (g0 + q) * 2048 + 1024, 0);
+                }
+                add16(c4, v4);
             }
         }
         K2_TICK(t_apply);
@@ -258,7 +278,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
                     if (nin > 2) hit(__builtin_amdgcn_readlane((int)e23.x, l), __builtin_amdgcn_readlane((int)e23.y, l));
                     if (nin > 3) hit(__builtin_amdgcn_readlane((int)e23.z, l), __builtin_amdgcn_readlane((int)e23.w, l));
                     for (int k = 4; k < nin; ++k) {
-                        const uint2 e = rows[((size_t)t * 64 + l) * D + k];
+                        const uint2 e = rows[((size_t)t * 64 + l) * W + k];
                         hit(e.x, e.y);
                     }
                 }
@@ -312,9 +332,9 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         cnt += __popcll(m);
         if (!on) continue;
         double acc = 0.0;
-        for (int k = 0; k < D; ++k) {
-            const uint32_t cc = a.ell_col[((size_t)t * D + k) * 64 + lane];
-            const size_t at = ((size_t)t * D + k) * 64 + lane;
+        for (int k = 0; k < W; ++k) {
+            const uint32_t cc = a.ell_col[((size_t)t * W + k) * 64 + lane];
+            const size_t at = ((size_t)t * W + k) * 64 + lane;
             const double vv = a.ell_val64 ? a.ell_val64[at] : (double)a.ell_val[at];
             const bool xc = XB ? (lds[cc] != 0) : (bool)((xm[cc >> 6] >> (cc & 63u)) & 1ull);
             if (xc) acc += vv;
@@ -459,12 +479,21 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                         hb = hb + ((lj == lb) ? cur.val[k] : 0.0f);
                     }
                 } else {
-                    for (int k = 0; k < W; ++k) {            // padding entries: (the variable itself, +0.0f)
-                        const size_t at = ((size_t)cur.slot * W + k) * 64 + lane;
-                        const int lj = lab[a.ell_col[at]];
-                        const float v = a.ell_val[at];
-                        ha = ha + ((lj == la) ? v : 0.0f);
-                        hb = hb + ((lj == lb) ? v : 0.0f);
+                    for (int k0 = 0; k0 < W; k0 += 16) {     // padding entries: (the variable itself, +0.0f)
+                        uint32_t cj[16];
+                        float vj[16];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {       // 32 loads in flight, then the gathers, then the sums
+                            const size_t at = ((size_t)cur.slot * W + k0 + k) * 64 + lane;
+                            cj[k] = a.ell_col[at];
+                            vj[k] = a.ell_val[at];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const int lj = lab[cj[k]];
+                            ha = ha + ((lj == la) ? vj[k] : 0.0f);
+                            hb = hb + ((lj == lb) ? vj[k] : 0.0f);
+                        }
                     }
                 }
             };
@@ -677,10 +706,12 @@ int mi_launch_csr_rank1(const EllArgs &a, hipStream_t st)
         if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, true>, a, bytes, st);
         if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, true>, a, bytes, st);
         if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, true>, a, bytes, st);
+        if (a.D > 64 && a.D % 16 == 0) return launch_csr_rank1(k_anneal_csr_rank1<0, true>, a, bytes, st);
     } else {
         if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, false>, a, bits, st);
         if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, false>, a, bits, st);
         if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, false>, a, bits, st);
+        if (a.D > 64 && a.D % 16 == 0) return launch_csr_rank1(k_anneal_csr_rank1<0, false>, a, bits, st);
     }
     return fail(MI_EUNSUPPORTED, "slot-ELL width %d not built", a.D);
 }

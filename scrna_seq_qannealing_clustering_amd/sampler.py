@@ -222,9 +222,9 @@ class MI355XSampler:
             raise ValueError("kernel must be 'auto', 'dense' or 'csr'")
         # structured models (sparse couplings + one uniform pair term: every graph-partition QUBO of the
         # reference) run on the CSR kernel at any size -- it is the faster one and needs no n x n matrix;
-        # general QUBOs, and rows wider than the 64-entry adjacency layout, run on the dense kernels (n <= 65536)
+        # (rows wider than 64 neighbours on its runtime-width form); general QUBOs run on the dense kernels (n <= 65536)
         max_deg = int(np.diff(model.rowptr).max()) if n else 0
-        use_csr = (kernel == "csr") or (kernel == "auto" and model._dense is None and (max_deg <= 64 or n > 65536))
+        use_csr = (kernel == "csr") or (kernel == "auto" and model._dense is None and (max_deg <= 4096 or n > 65536))
         if use_csr and model._dense is not None:
             raise ValueError("kernel='csr' needs a structured (CSR + uniform pair) model")
         if use_csr:

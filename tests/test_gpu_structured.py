@@ -289,13 +289,10 @@ def test_structured_error_behaviour():
     with pytest.raises(_lib.MiSaError):
         p.anneal(1, [1.0], 1, initial_states=np.array([[0, 7]], dtype=np.uint16))      # label >= K
     p.close()
-    # degree > 64 is outside the slot-ELL width
-    n = 70
-    rp = np.arange(0, n * (n - 1) + 1, n - 1, dtype=np.int32)
-    cc = np.array([j for i in range(n) for j in range(n) if j != i], dtype=np.int32)
-    with pytest.raises(_lib.MiSaError) as ei:
-        Problem.csr_rank1(rp, cc, np.ones(len(cc), dtype=np.float32), np.zeros(n, dtype=np.float32), 0.0)
-    assert ei.value.code == -5
+    # rows wider than 64 run on the runtime-width kernels (test_rows_wider_than_64); self-loops are refused
+    with pytest.raises(_lib.MiSaError):
+        Problem.csr_rank1(np.array([0, 1, 2], dtype=np.int32), np.array([0, 0], dtype=np.int32), val,
+                          np.zeros(2, dtype=np.float32), 0.0)
 
 
 def _csr_from_edges(n, edges, w):
@@ -573,9 +570,9 @@ def test_structured_kernels_random_models(seed):
 
 @pytest.mark.parametrize("n,max_deg,K", [(200, 100, 3), (700, 300, 8), (130, 129, 15)])
 @pytest.mark.parametrize("order", [None, "slots"])
-def test_potts_rows_wider_than_64(n, max_deg, K, order):
-    """k-way models whose rows exceed the 64-entry register layout (the reference's UNTRIMMED SNN graphs reach
-    degrees of order k^2; (130, 129) is a complete graph): K3's runtime-width form against the oracle."""
+def test_rows_wider_than_64(n, max_deg, K, order):
+    """Models whose rows exceed the 64-entry register layout (the reference's UNTRIMMED SNN graphs reach degrees
+    of order k^2; (130, 129) is a complete graph): the runtime-width forms of K3 and K2 against the oracle."""
     rs = np.random.RandomState(n + max_deg)
     if max_deg >= n - 1:
         edges = [(i, j) for i in range(n) for j in range(i + 1, n)]
@@ -616,6 +613,18 @@ def test_potts_rows_wider_than_64(n, max_deg, K, order):
     assert np.array_equal(lab, olab[:, back]) and info["accepted"] == int(ostats[1]) > 0
     assert np.allclose(en, _potts_host_energy(rowptr, col, val.astype(np.float64), 0.01, 0.0, lab.astype(np.int64), K),
                        rtol=1e-12, atol=1e-9)
-    # the binary kernel keeps its 64-entry limit (the sampler routes such models to the dense kernels)
-    with pytest.raises(_lib.MiSaError):
-        Problem.csr_rank1(rowptr, col, val, np.zeros(n, dtype=np.float32), 0.0)
+    # the binary kernel on the same wide rows
+    lin = rs.normal(scale=0.5, size=n).astype(np.float32)
+    with Problem.csr_rank1(rowptr, col, val, lin, 0.02, order=order,
+                           energy_model=(val.astype(np.float64), lin.astype(np.float64), 0.02)) as p:
+        p.anneal(R, betas, 18, replica_offset=3)
+        st, en, info = p.fetch()
+        perm = p.perm
+    if perm is None:
+        o_args, back = (rowptr, col, val, lin, 0.02), slice(None)
+    else:
+        rp2, c2, v2 = models.permute_csr(rowptr, col, val, perm)
+        o_args, back = (rp2, c2, v2, lin[perm], 0.02), np.argsort(perm)
+    ost, oen, ostats = so.sa_csr_rank1_philox(*o_args, R, betas, 18, replica_offset=3)
+    assert np.array_equal(st, ost[:, back]) and info["accepted"] == int(ostats[1]) > 0
+    assert np.allclose(en, oen, rtol=1e-6, atol=1e-6)
