@@ -59,3 +59,28 @@ def test_argument_validation():
             snn.build_snn(X, bad["k"])
     with pytest.raises(_lib.MiSaError):
         snn.build_snn(np.zeros((10, 65), dtype=np.float32), 3)
+
+
+def test_untrimmed_graph_through_both_structured_kernels():
+    """The reference's graph type 0 (no trim, main.py:88): rows of up to several hundred neighbours, built on the
+    GPU and annealed by the runtime-width forms of K2 (balanced cut) and K3 (k-way) behind the sampler."""
+    from scrna_seq_qannealing_clustering_amd import MI355XSampler, build_bqm_qubo, build_dqm_potts
+    rs = np.random.RandomState(4)
+    truth = np.repeat([0, 1, 2], 200)
+    X = (rs.normal(scale=6.0, size=(3, 12))[truth] + rs.normal(size=(600, 12))).astype(np.float32)
+    g = snn.build_snn(X, 12, 0.0, None)
+    assert g.max_degree > 64                                     # wider than the register-resident layout
+    G = g.to_graph()
+    sampler = MI355XSampler()
+    ss = sampler.sample_dqm(build_dqm_potts(G, 3, 0.005), num_reads=32, num_sweeps=300, seed=1)
+    assert ss.info["kernel"] == "potts_csr"
+    lab = np.array([ss.first.sample[v] for v in G.nodes])
+    # the three blobs are disconnected in the SNN graph: one label each
+    assert all(len(set(lab[truth == c])) == 1 for c in range(3)) and len(set(lab)) == 3
+    m = build_bqm_qubo(G, 0.05)
+    sb = sampler.sample_qubo(m, num_reads=64, num_sweeps=1000, seed=1)
+    assert sb.info["kernel"] == "csr_rank1"                      # no n x n matrix needed
+    x = np.array([sb.first.sample[v] for v in G.nodes])
+    assert sb.first.energy == pytest.approx(float(m.energies(x[None, :])[0]), rel=1e-12)
+    planted = (truth == 0).astype(np.int8)                       # one blob against the other two: cut 0
+    assert sb.first.energy <= float(m.energies(planted[None, :])[0]) + 1e-6    # at least as good as the planted cut
