@@ -33,13 +33,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_CELLS, K_NN, DIM, ORD, N_CLUSTERS = 2638, 5, 15, 15, 9
+SPREAD = 3.0        # cluster spread of the surrogate: the clusters overlap, ONE connected component (as real SNN graphs have a giant one)
 REPLICAS_PER_GPU, SWEEPS, SEED = 4096, 1000, 1234
 HBM_PEAK_GBPS = 8000.0
 
 
 def build_workload():
     from scrna_seq_qannealing_clustering_amd import graphs, models
-    nodes, eu, ev, w, _ = graphs.synthetic_snn(N_CELLS, K_NN, DIM, ORD, N_CLUSTERS, seed=0)
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(N_CELLS, K_NN, DIM, ORD, N_CLUSTERS, seed=0, spread=SPREAD)
     G = graphs.EdgeListGraph(nodes, eu, ev, w)
     m = models.build_bqm_qubo(G, 0.05, k=8)
     Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))

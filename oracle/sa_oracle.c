@@ -110,7 +110,41 @@ float orc_neglog_u(uint32_t r)
     p = fmaf(p, t, -0x1.00007cp-1f);
     p = fmaf(p, t, 0x1.fffffep-1f);
     float lnm = p * t;
-    return fmaf(-(float)e, 0x1.62e43p-1f, -lnm);
+    return fmaf((float)(-e), 0x1.62e43p-1f, -lnm);   /* (float)(-e), not -(float)e: +0 at u = 1 (e = 0, lnm = 0) */
+}
+
+/* The same value with the range reduction written the way the device kernels do it (csrc/mi_sa_device.h
+ * neglog_u): adding 2^23 - 0x3504f4 to the bits of u carries into the exponent field exactly when the mantissa
+ * exceeds that of 1.41421356f.  orc_neglog_forms_differ() counts the inputs (of all 2^23) on which the two
+ * forms return different bits: 0. */
+float orc_neglog_u_carry(uint32_t r)
+{
+    union { uint32_t u; float f; } cv;
+    cv.u = 0x3f800000u | (r >> 9);
+    cv.f = 2.0f - cv.f;
+    const uint32_t ub = cv.u;
+    const int neg_e = 127 - (int)((ub + 0x004afb0cu) >> 23);
+    cv.u = ub + ((uint32_t)neg_e << 23);
+    const float t = cv.f - 1.0f;
+    float p = -0x1.9f9af6p-4f;
+    p = fmaf(p, t, 0x1.4cd8dcp-3f);
+    p = fmaf(p, t, -0x1.61491cp-3f);
+    p = fmaf(p, t, 0x1.977bcp-3f);
+    p = fmaf(p, t, -0x1.ff611p-3f);
+    p = fmaf(p, t, 0x1.555a22p-2f);
+    p = fmaf(p, t, -0x1.00007cp-1f);
+    p = fmaf(p, t, 0x1.fffffep-1f);
+    return fmaf((float)neg_e, 0x1.62e43p-1f, -(p * t));
+}
+
+long orc_neglog_forms_differ(void)
+{
+    long bad = 0;
+    for (uint32_t k = 0; k < (1u << 23); ++k) {
+        const float a = orc_neglog_u(k << 9), b = orc_neglog_u_carry(k << 9);
+        if (memcmp(&a, &b, sizeof a) != 0) ++bad;
+    }
+    return bad;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -18,9 +18,10 @@ ap.add_argument("--n", type=int, default=2638)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--order", default=None)
+ap.add_argument("--spread", type=float, default=3.0, help="cluster spread of the surrogate graph (3.0 = bench.py workload)")
 ap.add_argument("arms", nargs="*", default=["k2_waves=0"])
 a = ap.parse_args()
-nodes, eu, ev, w, _ = graphs.synthetic_snn(a.n, 5, 15, 15, 9, seed=0)
+nodes, eu, ev, w, _ = graphs.synthetic_snn(a.n, 5, 15, 15, 9, seed=0, spread=a.spread)
 G = graphs.EdgeListGraph(nodes, eu, ev, w)
 m = models.build_bqm_qubo(G, 0.05, k=8)
 betas = models.make_beta_schedule(a.sweeps, models.default_beta_range(m))

@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -390,7 +391,13 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
             // K2's register image of a slot: groups of four (neighbour, value) per lane, the neighbour already
             // translated into where its state bit lives in LDS (the state masks start at LDS address 0)
             const int G = D / 4;
-            p->k2_state_bytes = ((size_t)slots * 64 * 16 <= 144 * 1024) ? 1 : 0;     // n <= 9216
+            // state in LDS: a half per variable while 16 replicas fit one CU (n <= 4608), else a byte (n <= 9216), else a bit
+            // (MI_K2_STATE = bit | byte | half narrows the choice: A/B timing of the three forms on one model)
+            const char *force = getenv("MI_K2_STATE");
+            const bool fits_half = (size_t)slots * 128 * 16 <= 144 * 1024, fits_byte = (size_t)slots * 64 * 16 <= 144 * 1024;
+            p->k2_state_bytes = fits_half ? 2 : (fits_byte ? 1 : 0);
+            if (force && !strcmp(force, "byte") && fits_byte) p->k2_state_bytes = 1;
+            if (force && !strcmp(force, "bit")) p->k2_state_bytes = 0;
             std::vector<uint32_t> ha((size_t)slots * G * 2 * 64 * 4, 0u), hf((size_t)slots, 0u);
             for (int t = 0; t < slots; ++t)
                 for (int lane = 0; lane < 64; ++lane) {
@@ -400,7 +407,13 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
                         uint32_t vb;
                         memcpy(&vb, &hv[((size_t)t * D + k) * 64 + lane], 4);
                         const size_t base = (((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3);
-                        ha[base] = p->k2_state_bytes ? c : ((((c >> 5) * 4u) << 8) | (c & 31u));
+                        if (getenv("MI_K2_DEBUG_LINEAR")) {       // TIMING ONLY (wrong chain): conflict-free gathers
+                            ha[base] = (uint32_t)((lane * 2 + ((k * 128) % (slots * 128))));
+                            ha[base + 256] = vb;
+                            continue;
+                        }
+                        ha[base] = p->k2_state_bytes == 2 ? 2u * c
+                                 : (p->k2_state_bytes == 1 ? c : ((((c >> 5) * 4u) << 8) | (c & 31u)));
                         ha[base + 256] = vb;
                     }
                 }
@@ -428,7 +441,8 @@ int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col
     rc = problem_common_init(p, device);
     if (!rc) rc = upload_slot_ell(p, rowptr, col, val, n);
     if (!rc) rc = [&]() -> int {
-        std::vector<float> hl((size_t)p->slots * 64, 0.0f);
+        // the lanes past n carry lin = +inf: their dE is +inf, never accepted (K2 has no per-lane bound check)
+        std::vector<float> hl((size_t)p->slots * 64, INFINITY);
         for (int i = 0; i < n; ++i) hl[i] = lin[i];
         HIP_TRY(hipMalloc((void **)&p->d_lin, hl.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(p->d_lin, hl.data(), hl.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -30,10 +30,13 @@ constexpr uint32_t PH_W0 = 0x9E3779B9u, PH_W1 = 0xBB67AE85u;
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4])
 {
+    // both halves of each 32 x 32 product from ONE v_mad_u64_u32 (3.3 issue cycles against 2 x 3.1 for
+    // v_mul_hi_u32 + v_mul_lo_u32, scripts/ubench_valu.hip)
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(PH_M0, c0), lo0 = PH_M0 * c0;
-        const uint32_t hi1 = __umulhi(PH_M1, c2), lo1 = PH_M1 * c2;
+        const uint64_t p0 = (uint64_t)PH_M0 * c0, p1 = (uint64_t)PH_M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += PH_W0; k1 += PH_W1;
@@ -42,14 +45,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // -ln(u), u in (0,1] from the top 23 bits of r; every step one IEEE fp32 op or fma (bit-reproducible).
+// Range reduction without a compare/select pair: adding C = 2^23 - 0x3504f4 to the bits of u carries into the
+// exponent field exactly when the mantissa exceeds that of 1.41421356f, which is the oracle's
+// `if (m > 1.41421356f) { m *= 0.5f; e += 1; }` (both forms are exact; checked over all 2^23 inputs by
+// tests/test_oracle_kat.py::test_neglog_reduction_forms_agree on the CPU restatement of this sequence).
 __device__ __forceinline__ float neglog_u(uint32_t r)
 {
     const float mm = __uint_as_float(0x3f800000u | (r >> 9));
     const float u = 2.0f - mm;
     const uint32_t ub = __float_as_uint(u);
-    int e = (int)(ub >> 23) - 127;
-    float m = __uint_as_float((ub & 0x007fffffu) | 0x3f800000u);
-    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const int neg_e = 127 - (int)((ub + 0x004afb0cu) >> 23);           // -(e), e as the oracle counts it
+    const float m = __uint_as_float(ub + ((uint32_t)neg_e << 23));     // u * 2^(-e) in [sqrt(1/2), sqrt(2))
     const float t = m - 1.0f;
     float p = -0x1.9f9af6p-4f;
     p = __fmaf_rn(p, t, 0x1.4cd8dcp-3f);
@@ -60,7 +66,7 @@ __device__ __forceinline__ float neglog_u(uint32_t r)
     p = __fmaf_rn(p, t, -0x1.00007cp-1f);
     p = __fmaf_rn(p, t, 0x1.fffffep-1f);
     const float lnm = p * t;
-    return __fmaf_rn(-(float)e, 0x1.62e43p-1f, -lnm);
+    return __fmaf_rn((float)neg_e, 0x1.62e43p-1f, -lnm);
 }
 
 __device__ __forceinline__ float readlane_f(float v, int l)

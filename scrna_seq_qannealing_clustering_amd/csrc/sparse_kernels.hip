@@ -51,12 +51,16 @@ __device__ __forceinline__ void slot_words(uint32_t (&w)[4], int tg, int lane, u
 #define K2_TICK(var) do { } while (0)
 #endif
 
-// XB: the state lives in LDS as one BYTE per variable (small models: 16 replicas x n bytes fit a CU) instead of
-// one bit: a neighbour's state is then a ds_read_u8 at its index and enters the field sum as fma(val, x, g) --
-// two VALU instructions per neighbour instead of four (address shift, bit extract, mask, add).
-template <int D, bool XB>
+// XS: how the state lives in LDS.  0: one BIT per variable (any n).  1: one BYTE per variable (16 replicas x n
+// bytes fit a CU): a neighbour's state is a ds_read_u8 at its index and enters the field sum as fma(val, x, g) --
+// two VALU instructions per neighbour (convert, fma) instead of four (address shift, bit extract, mask, add).
+// 2: one HALF per variable (0.0 / 1.0; n <= 4608): the fma takes the half as it is (v_fma_mix_f32 widens the
+// operand exactly), ONE VALU instruction per neighbour, the same fp32 result bit for bit.
+template <int D, int XS>
 __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllArgs a)
 {
+    constexpr bool XB = XS != 0;                     // state addressed per variable (byte or half), not per bit
+    typedef _Float16 half_t;
     // ONE wavefront per workgroup: the replica's state masks start at LDS address 0, so the host can store
     // every neighbour as a ready-made (LDS byte offset of its 32-bit state word << 8 | bit position).
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -74,7 +78,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         for (int t = 0; t < slots; ++t) {
             const int i = t * 64 + lane;
             const uint64_t m = __ballot(i < n && init[(size_t)r * n + i]);
-            if constexpr (XB) lds[i] = (char)((m >> lane) & 1ull);
+            if constexpr (XS == 2) reinterpret_cast<half_t *>(lds)[i] = (half_t)(float)((m >> lane) & 1ull);
+            else if constexpr (XS == 1) lds[i] = (char)((m >> lane) & 1ull);
             else if (lane == 0) xm[t] = m;
             S += __popcll(m);
         }
@@ -87,7 +92,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
                 const int t = 4 * tg + c;
                 if (t >= slots) break;
                 const uint64_t m = __ballot(t * 64 + lane < n && (w[c] >> 31));
-                if constexpr (XB) lds[t * 64 + lane] = (char)((m >> lane) & 1ull);
+                if constexpr (XS == 2) reinterpret_cast<half_t *>(lds)[t * 64 + lane] = (half_t)(float)((m >> lane) & 1ull);
+                else if constexpr (XS == 1) lds[t * 64 + lane] = (char)((m >> lane) & 1ull);
                 else if (lane == 0) xm[t] = m;
                 S += __popcll(m);
             }
@@ -141,31 +147,43 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         const uint32_t wc = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
         const int i = t * 64 + lane;
         const bool general = __builtin_amdgcn_readfirstlane((int)cur.flag) != 0;   // some variable of this slot has a
-        uint32_t metav = 0u;                                  // neighbour inside the slot
-        uint4 e01 = make_uint4(0u, 0u, 0u, 0u), e23 = e01;
-        if (general) {
-            metav = a.meta[i];
-            e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * W);
-            e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * W + 2);
-        }
+                                                              // neighbour inside the slot
         K2_TICK(t_init);
+        // this lane's own state word goes first (conflict-free: consecutive lanes, consecutive cells); it is back by
+        // the time the neighbour gathers are
+        uint32_t own = 0u;
+        if constexpr (XS == 2) own = reinterpret_cast<const uint16_t *>(lds)[i];      // 0x0000 / 0x3c00 (half 0.0 / 1.0)
+        else if constexpr (XS == 1) own = (uint32_t)(unsigned char)lds[i];            // 0 / 1
         // fresh field: lin_i + the stored neighbours whose bit is set, in stored order.  A clear bit adds +0.0f
         // (value AND mask): x + 0.0f == x for every x except -0.0f, and +-0.0f are the same number to every
         // comparison downstream -- no decision can differ from the oracle's skip.
         float gi = __uint_as_float(cur.lin);
         auto add16 = [&](const u32x4 *c4, const u32x4 *v4) {  // 16 state words in flight, then 16 adds
             uint32_t word[16];
+            // The gathers are written out: one wavefront per workgroup and no static LDS put the state at LDS
+            // address 0, so the packed neighbour word IS the address -- hipcc adds the (zero) base of the dynamic
+            // LDS block to every one of them with a v_add_u32.  The compiler does not count asm LDS reads: the wait
+            // that names all 16 destinations follows them (cdna_hip_programming.md 5.7, form ii).
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint32_t pk = c4[k / 4][k & 3];
-                if constexpr (XB) word[k] = (uint32_t)(unsigned char)lds[pk];           // packed word = the index
-                else word[k] = *reinterpret_cast<const uint32_t *>(lds + (pk >> 8));
+                if constexpr (XS == 2) asm volatile("ds_read_u16 %0, %1" : "=v"(word[k]) : "v"(pk));       // 2 * index
+                else if constexpr (XS == 1) asm volatile("ds_read_u8 %0, %1" : "=v"(word[k]) : "v"(pk));   // the index
+                else asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"(pk >> 8));
             }
-            asm volatile("" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(word[4]), "+v"(word[5]),
+                           "+v"(word[6]), "+v"(word[7]), "+v"(word[8]), "+v"(word[9]), "+v"(word[10]), "+v"(word[11]),
+                           "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15])
+                         :: "memory");
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint32_t pk = c4[k / 4][k & 3];
-                if constexpr (XB) {
+                if constexpr (XS == 2) {
+                    // the half widens exactly: fma(val, x, g), one rounding (v_fma_mix_f32)
+                    const half_t hx = __builtin_bit_cast(half_t, (uint16_t)word[k]);
+                    gi = __builtin_fmaf(__uint_as_float(v4[k / 4][k & 3]), (float)hx, gi);
+                } else if constexpr (XS == 1) {
                     // fma(val, 1, g) = g + val and fma(val, 0, g) = g: the oracle's conditional add, one rounding
                     gi = __fmaf_rn(__uint_as_float(v4[k / 4][k & 3]), (float)word[k], gi);
                 } else {
@@ -190,69 +208,66 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
             }
         }
         K2_TICK(t_apply);
-        float thr = neglog_u(wc) * T;
-        if (i >= n) thr = -INFINITY;
+        // (the lanes past n carry lin = +inf: dE = +inf is never below any threshold, no per-lane bound check here)
+        const float thr = neglog_u(wc) * T;
         uint64_t xm_t;                                        // the slot's 64 state bits as a scalar
-        if constexpr (XB) {
-            xm_t = __ballot(lds[i] != 0);
+        uint32_t xi;
+        if constexpr (XS == 2) {
+            xm_t = __ballot(own != 0u);
+            xi = own >> 13;                                   // 0x3c00 -> 1
+        } else if constexpr (XS == 1) {
+            xm_t = __ballot(own != 0u);
+            xi = own;
         } else {
             const uint64_t xm_v = xm[t];                      // same word in every lane: make it scalar
             xm_t = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xm_v >> 32)) << 32) |
                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xm_v);
+            xi = (uint32_t)((xm_t >> lane) & 1ull);
         }
-        const uint32_t xi = (uint32_t)((xm_t >> lane) & 1ull);
         const uint32_t sgnbit = xi << 31;                     // dE = x ? -f : f
         uint64_t todo = ~0ull, flipped = 0ull;
+        bool mine = false;                                    // this lane's variable flips in this slot
         if (!general) {
             // ---- no variable of this slot has a neighbour inside it: decisions depend on s alone -------------
-            // dE_i(u) = +-(g_i + c*u), u = (float)(s - x_i), is monotone in u (fp32 rounding is monotone), so
-            // "lane i accepts" is a half-line in s.  Its end point is found by bisecting the EXACT fp32
-            // predicate over the 127 values s can take inside this slot (|s - s0| <= 63), and the serial loop
-            // becomes integer.  The sign of the move is folded into both operands (negation is exact):
-            //     dE(u) = gs + cs*u,  gs = +-g_i, cs = +-c;  non-decreasing in u iff cs >= 0.
+            // Sequentially, lane i sees s = S + d_i with d_i = sum over the ACCEPTING lanes j < i of (+1 if x_j = 0,
+            // -1 if x_j = 1), and accepts iff  +-(g_i + c (float)(S + d_i - x_i)) < thr_i  (the oracle's expression,
+            // one multiply and one add).  That recurrence has exactly one solution -- the accept mask A of the
+            // sequential sweep -- and it is found WITHOUT the serial loop: evaluate every lane at once under a
+            // guessed mask, rebuild the mask, repeat until it reproduces itself.  After k rounds the lowest k lanes
+            // are final (induction over the lane index), so the fixed point is reached in at most 65 rounds whatever
+            // the data; on the SNN models it takes 2-3 (one round finds the mask at d = 0, the next ones only move
+            // the few lanes whose threshold lies within |d_i| of the current sum), against up to 64 trips through a
+            // dependent vector -> scalar -> vector chain.  Every round evaluates the exact fp32 predicate, so the
+            // decisions are the oracle's bit for bit.
+            //   d_i = popc_below_i(A ^ X) - popc_below_i(X)     (X = the slot's state mask)
+            // because a lane with x_j = 0 contributes A_j and one with x_j = 1 contributes (1 - A_j) - 1.
             const float gs = __uint_as_float(__float_as_uint(gi) ^ sgnbit);
             const float cs = __uint_as_float(__float_as_uint(a.c_pair) ^ sgnbit);
-            const float sig = (cs < 0.0f) ? -1.0f : 1.0f;     // accepts iff sig*(s - s0) <= J
-            const float u0 = (float)(S - (int)xi);
-            float U = __fmaf_rn(sig, -64.0f, u0);             // "never": one below the window
-#pragma unroll
-            for (int step = 64; step >= 1; step >>= 1) {
-                const float Uc = __fmaf_rn(sig, (float)step, U);      // small integers: exact
-                const float dE = gs + cs * Uc;
-                U = (dE < thr) ? Uc : U;
-            }
-            const int Ji = (int)(sig * (U - u0));             // in [-64, 63]
-            const int lo = (cs < 0.0f) ? -Ji : -64;           // accepts iff lo <= s - s0 <= lo + width
-            const unsigned int width = (unsigned int)(Ji + 64);
+            const int s_own = S - (int)xi;
             K2_TICK(t_pre);
-            // The serial loop, hand-scheduled: with four wavefronts per SIMD it is bound by SCALAR issue (one
-            // SALU instruction per SIMD every four cycles), and hipcc spends 16 scalar instructions per flip
-            // on it.  q = (s - s0) - lo per lane.
-            unsigned int q = (unsigned int)(0 - lo);
-            int l_s, d_s;
-            // The lanes above the last flipped one are selected by EXEC itself (v_cmp leaves the bits of inactive
-            // lanes clear), and the +-1 of a flip is read off the slot's state mask by the scalar unit: the only
-            // vector -> scalar hand-over per flip is the compare result.  6 SALU + 2 VALU, no lane-select hazard.
-            asm volatile(
-                "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
-                "s_cbranch_vccz 1f\n"
-                "0:\n\t"
-                "s_ff1_i32_b64 %[l], vcc\n\t"
-                "s_bitset1_b64 %[fl], %[l]\n\t"
-                "s_bitcmp1_b64 %[xm], %[l]\n\t"
-                "s_cselect_b32 %[d], -1, 1\n\t"
-                "s_lshl_b64 exec, -2, %[l]\n\t"
-                "v_add_u32 %[q], %[q], %[d]\n\t"
-                "v_cmp_le_u32 vcc, %[q], %[w]\n\t"
-                "s_cbranch_vccnz 0b\n"
-                "1:\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                : [q] "+v"(q), [fl] "+s"(flipped), [l] "=&s"(l_s), [d] "=&s"(d_s)
-                : [w] "v"(width), [xm] "s"(xm_t)
-                : "vcc", "scc");
+            mine = gs + cs * (float)s_own < thr;
+            uint64_t A = __ballot(mine);
+            if (A != 0ull) {                                  // wave-uniform
+                const int base = s_own - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(xm_t >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)xm_t, 0u));
+                for (int round = 0; round < 66; ++round) {
+                    const uint64_t Bm = A ^ xm_t;
+                    const int s_i = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(Bm >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)Bm, (uint32_t)base));
+                    mine = gs + cs * (float)s_i < thr;
+                    const uint64_t A2 = __ballot(mine);
+                    if (A2 == A) break;
+                    A = A2;
+                }
+            }
+            flipped = A;
             (void)todo;
             S += __popcll(flipped & ~xm_t) - __popcll(flipped & xm_t);
         } else {
+            // (slots with internal edges: none under the slot-independent order; their row heads are fetched here)
+            const uint32_t metav = a.meta[i];
+            const uint4 e01 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * W);
+            const uint4 e23 = *reinterpret_cast<const uint4 *>(rows + (size_t)i * W + 2);
             const uint64_t has_in = __ballot((metav & 0xffu) != 0u);
             float Sf = (float)(S - (int)xi);
             K2_TICK(t_pre);
@@ -286,7 +301,10 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         }
         if (flipped) {                                        // wave-uniform
             accepted += (unsigned long long)__popcll(flipped);
-            if constexpr (XB) { if ((flipped >> lane) & 1ull) lds[i] = (char)(xi ^ 1u); }
+            if (general) mine = (flipped >> lane) & 1ull;
+            // toggling a state cell is one XOR of the word read at the top of the slot
+            if constexpr (XS == 2) { if (mine) reinterpret_cast<uint16_t *>(lds)[i] = (uint16_t)(own ^ 0x3c00u); }
+            else if constexpr (XS == 1) { if (mine) lds[i] = (char)(own ^ 1u); }
             else if (lane == 0) xm[t] = xm_t ^ flipped;
         }
         K2_TICK(t_loop);
@@ -326,7 +344,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
     double e = 0.0;
     for (int t = 0; t < slots; ++t) {
         const int i = t * 64 + lane;
-        const uint64_t m = XB ? __ballot(lds[i] != 0) : xm[t];
+        const uint64_t m = XS == 2 ? __ballot(reinterpret_cast<const uint16_t *>(lds)[i] != 0)
+                                   : (XS == 1 ? __ballot(lds[i] != 0) : xm[t]);
         const int on = (int)((m >> lane) & 1ull);
         if (i < n) dst[i] = (uint8_t)on;
         cnt += __popcll(m);
@@ -336,7 +355,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
             const uint32_t cc = a.ell_col[((size_t)t * W + k) * 64 + lane];
             const size_t at = ((size_t)t * W + k) * 64 + lane;
             const double vv = a.ell_val64 ? a.ell_val64[at] : (double)a.ell_val[at];
-            const bool xc = XB ? (lds[cc] != 0) : (bool)((xm[cc >> 6] >> (cc & 63u)) & 1ull);
+            const bool xc = XS == 2 ? (reinterpret_cast<const uint16_t *>(lds)[cc] != 0)
+                                    : (XS == 1 ? (lds[cc] != 0) : (bool)((xm[cc >> 6] >> (cc & 63u)) & 1ull));
             if (xc) acc += vv;
         }
         e += (a.lin64 ? a.lin64[i] : (double)a.lin[i]) + 0.5 * acc;
@@ -701,17 +721,22 @@ int launch_csr_rank1(KernelT kernel, const EllArgs &a, size_t lds, hipStream_t s
 
 int mi_launch_csr_rank1(const EllArgs &a, hipStream_t st)
 {
-    const size_t bits = (size_t)a.slots * 8, bytes = (size_t)a.slots * 64;
-    if (a.state_bytes) {
-        if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, true>, a, bytes, st);
-        if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, true>, a, bytes, st);
-        if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, true>, a, bytes, st);
-        if (a.D > 64 && a.D % 16 == 0) return launch_csr_rank1(k_anneal_csr_rank1<0, true>, a, bytes, st);
+    const size_t bits = (size_t)a.slots * 8, bytes = (size_t)a.slots * 64, halves = (size_t)a.slots * 128;
+    if (a.state_bytes == 2) {
+        if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, 2>, a, halves, st);
+        if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, 2>, a, halves, st);
+        if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, 2>, a, halves, st);
+        if (a.D > 64 && a.D % 16 == 0) return launch_csr_rank1(k_anneal_csr_rank1<0, 2>, a, halves, st);
+    } else if (a.state_bytes == 1) {
+        if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, 1>, a, bytes, st);
+        if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, 1>, a, bytes, st);
+        if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, 1>, a, bytes, st);
+        if (a.D > 64 && a.D % 16 == 0) return launch_csr_rank1(k_anneal_csr_rank1<0, 1>, a, bytes, st);
     } else {
-        if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, false>, a, bits, st);
-        if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, false>, a, bits, st);
-        if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, false>, a, bits, st);
-        if (a.D > 64 && a.D % 16 == 0) return launch_csr_rank1(k_anneal_csr_rank1<0, false>, a, bits, st);
+        if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, 0>, a, bits, st);
+        if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, 0>, a, bits, st);
+        if (a.D == 64) return launch_csr_rank1(k_anneal_csr_rank1<64, 0>, a, bits, st);
+        if (a.D > 64 && a.D % 16 == 0) return launch_csr_rank1(k_anneal_csr_rank1<0, 0>, a, bits, st);
     }
     return fail(MI_EUNSUPPORTED, "slot-ELL width %d not built", a.D);
 }

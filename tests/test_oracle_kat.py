@@ -45,6 +45,13 @@ def test_chain_word_addressing():
         assert so.chain_word(seed, i, 7, 11, 0) == ref
 
 
+def test_neglog_reduction_forms_agree():
+    """The device's compare-free range reduction (csrc/mi_sa_device.h neglog_u) == the oracle's, on all 2^23 inputs."""
+    lib = so.lib()
+    lib.orc_neglog_forms_differ.restype = __import__("ctypes").c_long
+    assert lib.orc_neglog_forms_differ() == 0
+
+
 def test_neglog_matches_log():
     rng = np.random.RandomState(0)
     for r in list(rng.randint(0, 2 ** 32, size=2000, dtype=np.uint64)) + [0, 1, 511, 512, 2 ** 32 - 1]:
