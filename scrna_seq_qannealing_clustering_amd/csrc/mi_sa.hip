@@ -107,6 +107,7 @@ struct mi_sa_problem {
     uint2 *d_rows = nullptr;                 // K2: row-major adjacency, in-slot neighbours first
     uint32_t *d_meta = nullptr;              // K2: in-slot count | degree << 8
     uint4 *d_adj4 = nullptr;                 // K2: packed slot adjacency (see EllArgs::adj4)
+    uint4 *d_adj4p = nullptr;                // K2p (two replicas per wavefront): the same with neighbour word = 4 * index; null = not eligible
     uint32_t *d_slot_flags = nullptr;        // K2: slots with internal edges
     int k2_state_bytes = 0;                  // K2: byte-per-variable state (16 replicas x n bytes fit one CU's LDS)
     int cus = 0;
@@ -133,6 +134,7 @@ struct mi_sa_problem {
     int opt_debug = 0;                       // DenseArgs::debug (diagnostic timing only; results are wrong)
     int opt_min_cluster_size = 0;            // K3: hard lower bound on every cluster's size (CQM_clustering.py:46-48)
     int opt_k2_waves = 0;                    // K2: replicas per workgroup (0 = auto)
+    int opt_k2_pair = 0;                     // K2p: 0 auto (runs of >= 2048 replicas), 1 always when eligible, 2 never
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
     int last_launches = 1;                   // kernel launches that served the last anneal
@@ -421,6 +423,17 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
             HIP_TRY(hipMalloc((void **)&p->d_slot_flags, hf.size() * sizeof(uint32_t)));
             HIP_TRY(hipMemcpy(p->d_adj4, ha.data(), ha.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(p->d_slot_flags, hf.data(), hf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            // K2p: every slot free of internal edges, D = 16 / 32, 8 wavefronts x 4 bytes per variable fit a CU's LDS
+            bool any_general = false;
+            for (int t = 0; t < slots; ++t) any_general = any_general || hf[t] != 0u;
+            if (!any_general && (D == 16 || D == 32) && (size_t)slots * 256 * 8 <= 150 * 1024) {
+                for (int t = 0; t < slots; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int k = 0; k < D; ++k)
+                            ha[(((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3)] = 4u * hc[((size_t)t * D + k) * 64 + lane];
+                HIP_TRY(hipMalloc((void **)&p->d_adj4p, ha.size() * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpy(p->d_adj4p, ha.data(), ha.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
         }
     }
     return MI_OK;
@@ -502,7 +515,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -551,6 +564,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "debug")) { p->opt_debug = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_waves") && value >= 0 && value <= 16) { p->opt_k2_waves = (int)value; return MI_OK; }
+    if (!strcmp(key, "k2_pair") && value >= 0 && value <= 2) { p->opt_k2_pair = (int)value; return MI_OK; }
     if (!strcmp(key, "min_cluster_size") && value >= 0) {
         if (p->kind != MI_KIND_POTTS_CSR) return fail(MI_EINVAL, "min_cluster_size applies to Potts problems");
         p->opt_min_cluster_size = (int)value;
@@ -634,7 +648,14 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         }
         p->last_launches = 1;
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
-        rc = (p->kind == MI_KIND_POTTS_CSR) ? mi_launch_potts(a, p->stream) : mi_launch_csr_rank1(a, p->stream);
+        if (p->kind == MI_KIND_POTTS_CSR) {
+            rc = mi_launch_potts(a, p->stream);
+        } else if (p->d_adj4p && p->opt_k2_pair != 2 && (p->opt_k2_pair == 1 || R >= 2048)) {
+            a.adj4 = p->d_adj4p;                      // two replicas per wavefront: half the adjacency traffic per update
+            rc = mi_launch_csr_rank1_pair(a, p->stream);
+        } else {
+            rc = mi_launch_csr_rank1(a, p->stream);
+        }
         if (rc) return rc;
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
     }

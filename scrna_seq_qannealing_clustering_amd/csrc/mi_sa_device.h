@@ -243,6 +243,7 @@ struct EllArgs {
     double c_pair64;
 };
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
+int mi_launch_csr_rank1_pair(const EllArgs &, hipStream_t);     // sparse_pair_kernels.hip: two replicas per wavefront
 int mi_launch_potts(const EllArgs &, hipStream_t);
 
 // K1x (dense_xl_kernels.hip): dense chain for 4096 < n <= 65536, one workgroup per replica

@@ -162,6 +162,99 @@ def test_csr_rank1_slot_independent_order_and_integer_fast_path():
         assert np.array_equal(s_best, st[idx])
 
 
+def test_csr_rank1_two_replicas_per_wavefront():
+    """K2p (csrc/sparse_pair_kernels.hip): two replicas share one wavefront and one set of adjacency registers.  Same
+    chain as K2: equal to the oracle on the renumbered model and to the one-replica kernel, for an odd replica count
+    (one idle seat), given initial states, a run cut in two (MI_F_CONTINUE + sweep_offset), one constant temperature
+    per replica, a replica offset, the fp64 energy model; the wider (D = 32) adjacency as well."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    for (n, k, ordv, ncl, seed) in ((900, 5, 15, 5, 4), (700, 8, 30, 4, 6)):
+        nodes, eu, ev, w, _ = graphs.synthetic_snn(n, k, 15, ordv, ncl, seed=seed, spread=2.5)
+        m = models.build_bqm_qubo(graphs.EdgeListGraph(nodes, eu, ev, w), 0.05)
+        c_pair = float(np.float32(m.c_pair))
+        betas = np.geomspace(2e-3, 40.0, 30)
+        init = np.random.RandomState(1).randint(0, 2, size=(7, n)).astype(np.uint8)
+        with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), c_pair, order="slots",
+                               energy_model=(m.val, m.lin, m.c_pair)) as p:
+            perm = p.perm
+            rp, cc, vv = models.permute_csr(m.rowptr, m.col, f32(m.val), perm)
+            o_args = (rp, cc, vv, f32(m.lin)[perm], c_pair)
+            runs = {}
+            for mode in (1, 2):                                        # 1 = pair kernel, 2 = one replica per wavefront
+                p.set_option("k2_pair", mode)
+                p.anneal(7, betas, 8, replica_offset=5)
+                a = p.fetch()
+                p.anneal(7, betas, 8, initial_states=init)
+                b = p.fetch()
+                p.anneal(7, betas[:11], 8, initial_states=init)
+                p.anneal(7, betas[11:], 8, sweep_offset=11, continue_run=True)
+                c = p.fetch()
+                p.anneal(7, np.geomspace(0.01, 20.0, 7), 8, num_sweeps=9)
+                d = p.fetch()
+                runs[mode] = (a, b, c, d)
+                best = p.best()
+                assert best[1] == pytest.approx(d[1].min(), rel=1e-6)
+            for x, y in zip(runs[1], runs[2]):
+                assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2]["accepted"] == y[2]["accepted"]
+            a, b, c, d = runs[1]
+            assert np.array_equal(b[0], c[0]) and np.array_equal(b[1], c[1])
+        ost, _, ostats = so.sa_csr_rank1_philox(*o_args, 7, betas, 8, replica_offset=5)
+        assert np.array_equal(a[0][:, perm], ost) and a[2]["accepted"] == int(ostats[1])
+        assert np.allclose(a[1], m.energies(a[0]), rtol=1e-12, atol=1e-9)
+        ost, _, ostats = so.sa_csr_rank1_philox(*o_args, 7, betas, 8, init=np.ascontiguousarray(init[:, perm]))
+        assert np.array_equal(b[0][:, perm], ost) and b[2]["accepted"] == int(ostats[1])
+        ost, _, ostats = so.sa_csr_rank1_philox(*o_args, 7, np.geomspace(0.01, 20.0, 7), 8, num_sweeps=9)
+        assert np.array_equal(d[0][:, perm], ost) and d[2]["accepted"] == int(ostats[1])
+
+
+def test_full_size_properties_config2_csr_headline():
+    """BASELINE config 2 exactly as bench.py times it: bench.build_workload()'s model (n = 2638, one connected
+    component), Problem.csr_rank1(order="slots"), 4096 replicas x 1000 sweeps, seed 1234 -- the two-replicas-per-
+    wavefront kernel.  Beyond what the oracle runs in seconds, so: the oracle on three slices of the replicas
+    (states, accepted counts, fp64 energies, integer cut counts), the upper half-shard alone == the upper half of the
+    full run, the run cut in two == the run, energies == fp64 host evaluation in the caller's model."""
+    import bench
+    m, Qs, betas, (eu, ev, w), G = bench.build_workload()
+    n, R = m.num_variables, bench.REPLICAS_PER_GPU
+    assert n == 2638 and len(betas) == 1000
+    # the workload is ONE graph component: the optimum has to cut edges
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    ncomp, lab = connected_components(sp.coo_matrix((np.ones(len(eu)), (eu, ev)), shape=(n, n)), directed=False)
+    assert np.bincount(lab).max() >= 0.9 * n
+    c_pair = float(np.float32(m.c_pair))
+    with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), c_pair, order="slots",
+                           energy_model=(m.val, m.lin, m.c_pair)) as p:
+        perm = p.perm
+        p.anneal(R, betas, bench.SEED)
+        st, en, info = p.fetch()
+        idx, e_best, key, s_best = p.best()
+        p.anneal(R // 2, betas, bench.SEED, replica_offset=R // 2)
+        st_hi, en_hi, _ = p.fetch()
+        p.anneal(R, betas[:400], bench.SEED)
+        p.anneal(R, betas[400:], bench.SEED, sweep_offset=400, continue_run=True)
+        st_2, en_2, info_2 = p.fetch()
+    assert st.shape == (R, n) and info["proposals"] == R * 1000 * n
+    assert np.array_equal(st[R // 2:], st_hi) and np.array_equal(en[R // 2:], en_hi)
+    assert np.array_equal(st, st_2) and np.array_equal(en, en_2)
+    assert np.allclose(en, m.energies(st), rtol=1e-12, atol=1e-8)
+    assert en[idx] == en.min() and np.array_equal(s_best, st[idx])
+    cut = so.cut_edges(eu, ev, st)
+    assert int(cut[idx]) > 0                                           # a connected graph: the best state cuts edges
+    rp, cc, vv = models.permute_csr(m.rowptr, m.col, f32(m.val), perm)
+    acc = 0
+    for lo in (0, 2046, 4092):
+        ost, oen, ostats = so.sa_csr_rank1_philox(rp, cc, vv, f32(m.lin)[perm], c_pair, 4, betas, bench.SEED,
+                                                  replica_offset=lo)
+        back = ost[:, np.argsort(perm)]
+        assert np.array_equal(st[lo:lo + 4], back)
+        assert np.array_equal(cut[lo:lo + 4], so.cut_edges(eu, ev, back))
+        assert np.allclose(en[lo:lo + 4], m.energies(back), rtol=1e-12, atol=1e-8)
+        assert np.allclose(oen, en[lo:lo + 4], rtol=1e-5)              # the oracle's energies are the fp32 model's
+        acc += int(ostats[1])
+    assert 0 < acc < 12 * 1000 * n and 0 < info["accepted"] < info["proposals"]
+
+
 def test_potts_slot_independent_order():
     """K3 under order="slots": equal to the oracle on the renumbered model, labels returned in the caller's order."""
     from scrna_seq_qannealing_clustering_amd.sampler import default_potts_beta_range
