@@ -15,17 +15,24 @@ Multi-GPU: replicas shard (weak scaling: 4096 replicas per GPU, global ids rank*
 replicated, and each step ends with the ONE exchange the path has: a 64-bit MIN all-reduce of the
 packed (energy, replica id) key + a broadcast of the winner's labels (RCCL over xGMI).
 
-Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes per update (SURVEY.md section 8d:
-CSR deg_i*8 + 8 averaged over the variables; dense 4n) x updates per launch / mean launch time (HIP
-events).  The model (0.34 MB in CSR form, 27.8 MB dense) lives in L2 / Infinity Cache, so this is an
-effective-bandwidth figure; `traffic` is what the fabric counters saw.  `cpu_baseline` times the oracle's
-neal restatement on this host.
+Rank 0 prints one JSON line.  The model (0.34 MB in CSR form) lives in the L2s, never in HBM traffic terms, so the
+`roofline` object of the CSR kernel is an L2 roofline: `achieved` = bytes the kernel's loads request from L2
+per launch (adjacency + linear terms of every slot of every sweep of every wavefront, counted from the launch
+shape; the TCC_REQ counter of profiles/r02_* agrees) / mean launch time (HIP events), `peak` = 34.5 TB/s
+(MI355X_MICROARCH.md, L2 aggregate), `traffic` = what the fabric counters saw (HBM side).  `effective` keeps
+SURVEY.md 8d's per-update byte model (deg_i*8 + 8) as an effective-bandwidth figure with no fraction.  The one
+kernel that really streams Q from HBM (K1x, n = 50 000 dense) is reported under `other_kernels.dense_xl_50k`.
+`cpu_baseline` times the oracle on this host: the neal restatement (value), the SAME chain as the GPU kernel
+(`same_chain`) and the neal restatement at equal reads and sweeps (`equal_reads`).
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+# dmabuf IPC for RCCL on this driver: must be in the environment before the first HIP call of the process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 
@@ -36,6 +43,7 @@ N_CELLS, K_NN, DIM, ORD, N_CLUSTERS = 2638, 5, 15, 15, 9
 SPREAD = 3.0        # cluster spread of the surrogate: the clusters overlap, ONE connected component (as real SNN graphs have a giant one)
 REPLICAS_PER_GPU, SWEEPS, SEED = 4096, 1000, 1234
 HBM_PEAK_GBPS = 8000.0
+L2_PEAK_GBPS = 34500.0          # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s (8 XCDs x 4 MiB)
 
 
 def build_workload():
@@ -72,13 +80,24 @@ def real_neal_probe(Qs, betas):
             "best_energy": float(ss.first.energy), "sample": "real dwave-neal, 4 reads x %d sweeps, same Q" % sweeps}
 
 
-def cpu_baseline(Qs, betas, seconds_target=15.0):
-    """The oracle's restatement of dwave-neal (Ising, fp64, xorshift128+, sequential sweeps) on a bounded
-    sample of the SAME workload: same Q, every (len/sweeps)-th beta of the same schedule."""
+def cpu_baseline(m, Qs, betas, edges, gpu_states, gpu_energies, perm, seconds_target=12.0):
+    """The oracle on this host, on BOUNDED samples of the same workload:
+      value        the restatement of dwave-neal (fp64 Ising, xorshift128+, dense couplings as neal's adjacency
+                   lists would hold this QUBO, sequential sweeps) -- every (len/sweeps)-th beta of the schedule;
+      same_chain   the chain the GPU kernel runs (CSR + uniform pair term, fp32, Philox: oracle 2b) on the same
+                   threads -- the like-for-like algorithm (O(deg) per update instead of neal's O(n) per accepted flip);
+      equal_reads  neal restatement, 64 reads x the FULL schedule, against replicas 0..63 of the GPU run: best /
+                   mean energy (fp64, the caller's model) and the integer edge cut of the best state."""
     from oracle import sa_oracle as so
+    eu, ev = edges
     h, J, off = so.qubo_to_ising_dense(Qs.astype(np.float64))
     # the GPU box shares its host: one GPU's share is 16 cores (more threads only oversubscribe)
     cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), int(os.environ.get("MI_CPU_THREADS", "16")))
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     sweeps = 50
     sub = betas[:: max(1, len(betas) // sweeps)][:sweeps]
     # calibrate on 1 read, 1 thread ("how neal runs": reads are sequential, single-threaded)
@@ -90,52 +109,85 @@ def cpu_baseline(Qs, betas, seconds_target=15.0):
     t0 = time.perf_counter()
     _, en, st = so.sa_ising_neal_dense(h, J, reads, sub, seed=SEED, threads=cores)
     t = time.perf_counter() - t0
-    # energy at the SAME sweep count as the GPU run (the metric's "best QUBO energy vs neal"): one read per
-    # thread over the full schedule
+    # the GPU kernel's own chain on the CPU (the renumbered model the device runs)
+    from scrna_seq_qannealing_clustering_amd import models
+    rp, cc, vv = models.permute_csr(m.rowptr, m.col, m.val.astype(np.float32), perm)
+    lin = m.lin.astype(np.float32)[perm]
+    sc_reads, sc_sub = 8 * cores, betas[::10]
     t0 = time.perf_counter()
-    _, en_full, _ = so.sa_ising_neal_dense(h, J, cores, betas, seed=SEED + 1, threads=cores)
-    t_full = time.perf_counter() - t0
+    sc_st, sc_en, sc_stats = so.sa_csr_rank1_philox(rp, cc, vv, lin, float(np.float32(m.c_pair)), sc_reads, sc_sub, SEED)
+    t_sc = time.perf_counter() - t0
+    # equal reads, equal sweeps
+    R_eq = 64
+    t0 = time.perf_counter()
+    sp, _, _ = so.sa_ising_neal_dense(h, J, R_eq, betas, seed=SEED + 1, threads=cores)
+    t_eq = time.perf_counter() - t0
+    xn = ((sp + 1) // 2).astype(np.uint8)
+    e_neal = m.energies(xn)
+    cut_neal = so.cut_edges(eu, ev, xn)
+    e_gpu = np.asarray(gpu_energies[:R_eq])
+    cut_gpu = so.cut_edges(eu, ev, np.ascontiguousarray(gpu_states[:R_eq]))
     return {
         "value": float(st[0]) / t, "unit": "spin-flip updates/s", "cores": cores, "kind": "port",
         "single_thread_value": single,
         "best_energy": float((en + off).min()),
-        "same_sweeps": {"reads": cores, "sweeps": int(len(betas)), "best_energy": float((en_full + off).min()),
-                        "mean_energy": float((en_full + off).mean()), "seconds": t_full},
         "sample": "oracle neal restatement (fp64 Ising, xorshift128+), same dense Q, %d reads x %d sweeps "
                   "(every %d-th beta of the 1000-sweep schedule), OpenMP over reads on %d threads; "
                   "real dwave-neal is not installable offline" % (reads, len(sub), max(1, len(betas) // sweeps), cores),
         "seconds": t,
+        "same_chain": {"value": float(sc_stats[0]) / t_sc, "unit": "spin-flip updates/s", "cores": cores,
+                       "best_energy": float(sc_en.min()), "seconds": t_sc,
+                       "sample": "oracle 2b (the GPU kernel's chain: CSR + uniform pair, fp32, Philox), %d reads x %d sweeps "
+                                 "(every 10th beta), OpenMP over reads" % (sc_reads, len(sc_sub))},
+        "equal_reads": {"reads": R_eq, "sweeps": int(len(betas)), "seconds": t_eq,
+                        "neal_best_energy": float(e_neal.min()), "neal_mean_energy": float(e_neal.mean()),
+                        "neal_best_cut_edges": int(cut_neal[int(np.argmin(e_neal))]),
+                        "gpu_best_energy": float(e_gpu.min()), "gpu_mean_energy": float(e_gpu.mean()),
+                        "gpu_best_cut_edges": int(cut_gpu[int(np.argmin(e_gpu))]),
+                        "gpu_all_replicas_best_energy": float(np.min(gpu_energies)),
+                        "note": "same schedule, same number of reads and sweeps; the two chains have the same stationary "
+                                "distributions (Metropolis, sequential sweeps), so which best-of-64 is lower is chance; the "
+                                "means agree within their standard errors (tests/test_gpu_sampler.py)"},
         "real_neal": real_neal_probe(Qs, betas),         # null: not importable on this host
     }
 
 
-def pmc_traffic(replicas, sweeps, launches, kernel):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload
-    (profiles/r01_pmc_traffic.json, written by scripts/pmc_traffic.py on the GPU box: FETCH_SIZE doubled
-    per the gfx950 note + WRITE_SIZE, averaged over the launches of one step).  None when no profile matches
-    this launch shape."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def _profile_json(name):
     try:
-        rec = json.load(open(path))
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return None
-    if (rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("launches") == launches
-            and rec.get("kernel") == kernel):
+
+
+def pmc_traffic(replicas, sweeps, launches, kernel):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload
+    (profiles/r02_pmc_traffic.json, written by scripts/pmc_traffic.py on the GPU box: FETCH_SIZE doubled
+    per the gfx950 note + WRITE_SIZE, averaged over the launches of one step).  None when no profile matches
+    this launch shape and kernel."""
+    rec = _profile_json("r02_pmc_traffic.json")
+    if rec and (rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("launches") == launches
+                and rec.get("kernel") == kernel):
         return float(rec["hbm_bytes_per_launch"])
     return None
 
 
-def binding_resource(kernel):
-    """What actually binds the timed kernel, from the committed SQ-counter passes (profiles/r01_k2_binding.json,
-    scripts/pmc_k2.sh + scripts/k2_binding.py): the byte model of `roofline` is an effective-bandwidth figure
-    for a model that lives in L2."""
-    if not kernel.startswith("k_anneal_csr_rank1"):
-        return None
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_k2_binding.json")))
-    except (OSError, ValueError):
-        return None
-    return {k: rec[k] for k in ("resource", "utilisation", "salu_issue_utilisation", "l2_hit_rate", "source")}
+def binding_resource(kernel, replicas, sweeps):
+    """The counters of the committed SQ / TCC passes over this kernel at this launch shape
+    (profiles/r02_k2_binding.json, scripts/pmc_k2.sh + scripts/k2_binding.py): L2 request bytes, LDS busy, VALU and
+    per-wavefront issue.  None when the file was taken on another kernel or shape."""
+    rec = _profile_json("r02_k2_binding.json")
+    if rec and rec.get("kernel") == kernel and rec.get("replicas") == replicas and rec.get("sweeps") == sweeps:
+        return {k: rec[k] for k in rec if k not in ("kernel", "replicas", "sweeps")}
+    return None
+
+
+def l2_request_bytes_per_launch(kernel, R, sweeps, n, D):
+    """Bytes the anneal kernel's vector loads request from L2 in one launch: per slot of 64 variables the packed
+    adjacency (D entries x 64 lanes x (4 B neighbour + 4 B value)) and the linear terms (256 B); one wavefront
+    carries two replicas in the pair kernel, one otherwise.  Initial states / epilogue (once per launch) are left out."""
+    slots = (n + 63) // 64
+    waves = (R + 1) // 2 if "pair" in kernel else R
+    return float(waves) * sweeps * slots * (D * 64 * 8 + 256)
 
 
 def other_kernels(m, Qs, betas, graph, rank_device, headline):
@@ -150,16 +202,16 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
     b = models.make_beta_schedule(S, models.default_beta_range(m))
     if headline == "csr":
         p = Problem.dense(Qs, offset=0.0, device=rank_device)
-        name, kname = "dense_bqm", "k_anneal_dense_wg<44,4>"
+        name = "dense_bqm"
     else:
         p = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
                               float(np.float32(m.c_pair)), device=rank_device, order="slots")
-        name, kname = "csr_rank1_bqm", "k_anneal_csr_rank1<16, true>"
+        name = "csr_rank1_bqm"
     with p:
         p.anneal(R, b, SEED)
         ms = p.kernel_ms()
         st, en, info = p.fetch()
-        out[name] = {"kernel": kname, "replicas": R, "sweeps": S, "kernel_ms": ms,
+        out[name] = {"kernel": p.kernel_name(), "replicas": R, "sweeps": S, "kernel_ms": ms,
                      "updates_per_s": R * S * n / (ms * 1e-3),
                      "best_energy": float(m.energies(st[int(np.argmin(en))][None, :])[0]),
                      "acceptance": info["accepted"] / info["proposals"]}
@@ -170,7 +222,7 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
         p.anneal(R, b, SEED)
         ms = p.kernel_ms()
         lab, en, info = p.fetch()
-        out["potts_dqm_k8"] = {"kernel": "k_anneal_potts<16>", "replicas": R, "sweeps": S, "kernel_ms": ms,
+        out["potts_dqm_k8"] = {"kernel": p.kernel_name(), "replicas": R, "sweeps": S, "kernel_ms": ms,
                                "updates_per_s": R * S * n / (ms * 1e-3), "best_energy": float(en.min()),
                                "acceptance": info["accepted"] / info["proposals"]}
     # K4: the replica-batched energy x^T Q x of the headline's final states on the matrix cores (the one
@@ -186,7 +238,56 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
                           "frac_of_mfma_peak": flops / (ms * 1e-3) / 157.3e12,
                           "max_rel_diff_vs_exact_fp64": float(np.max(np.abs(e_mfma[:256] - e_exact) /
                                                                      np.maximum(1.0, np.abs(e_exact))))}
+    if os.environ.get("MI_BENCH_SKIP_50K") != "1":
+        out["dense_xl_50k"] = dense_xl_50k(rank_device)
     return out
+
+
+def dense_xl_50k(rank_device, n=50000, replicas=128, sweeps=8):
+    """BASELINE config 4 in its literal form -- the one kernel of the path that really streams Q from HBM: a
+    synthetic 50 000-cell SNN graph built on the GPU (snn.build_snn), the clustering_bqm QUBO as a dense fp32
+    matrix (10.6 GB resident in HBM), K1x (one workgroup per replica; an ACCEPTED flip streams one padded row of
+    Q), the first `sweeps` sweeps of the 1000-step schedule.  `hbm_roofline`: the 4 n-byte row model against the
+    8 TB/s spec peak; `fabric` = what rocprofv3 FETCH_SIZE x 2 saw on this shape (profiles/r02_dense50k.json) --
+    replicas walk the rows in the same order, so the Infinity Cache serves part of the row reads."""
+    from scrna_seq_qannealing_clustering_amd import models, snn
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    rng = np.random.RandomState(1)
+    centers = rng.normal(scale=4.0, size=(30, 15))
+    X = (centers[rng.randint(0, 30, size=n)] + rng.normal(size=(n, 15))).astype(np.float32)
+    t0 = time.perf_counter()
+    g = snn.build_snn(X, 5, 0.0, 15, device=rank_device)
+    m = models.build_bqm_qubo(g.to_graph(), 0.05)
+    Qs = np.full((n, n), np.float32(m.c_pair / 2.0), dtype=np.float32)          # Qs_ij = (c_pair + S_ij) / 2
+    rows = np.repeat(np.arange(n), np.diff(m.rowptr))
+    Qs[rows, m.col] += (m.val / 2.0).astype(np.float32)
+    Qs[np.arange(n), np.arange(n)] = m.lin.astype(np.float32)
+    t_build = time.perf_counter() - t0
+    betas = models.make_beta_schedule(1000, models.default_beta_range(m))[:sweeps]
+    t0 = time.perf_counter()
+    with Problem.dense(Qs, device=rank_device) as p:
+        t_upload = time.perf_counter() - t0
+        del Qs
+        p.anneal(replicas, betas, SEED)
+        ms = p.kernel_ms()
+        kname = p.kernel_name()
+        _, en, info = p.fetch(states=False)
+    n_pad = ((n + 4095) // 4096) * 4096
+    rows_streamed = info["accepted"] + replicas * n // 2          # + field initialisation: ~n/2 rows per replica
+    row_gbps = rows_streamed * 4.0 * n_pad / (ms * 1e-3) / 1e9
+    rec = _profile_json("r02_dense50k.json")
+    fabric = None
+    if rec and rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("n") == n:
+        fabric = {"GBps": rec["fabric_read_GBps"], "frac_of_hbm_peak": rec["fabric_read_GBps"] / HBM_PEAK_GBPS,
+                  "source": "profiles/r02_dense50k.json (rocprofv3 --pmc FETCH_SIZE x 2, same shape)"}
+    return {"kernel": kname, "n": n, "replicas": replicas, "sweeps": sweeps, "kernel_ms": ms,
+            "updates_per_s": replicas * sweeps * n / (ms * 1e-3), "acceptance": info["accepted"] / info["proposals"],
+            "dense_Q_bytes": 4 * n * n_pad, "graph_edges": int(len(m.col) // 2),
+            "hbm_roofline": {"bound": "hbm", "achieved": row_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": row_gbps / HBM_PEAK_GBPS,
+                             "model": "4 * n_pad bytes of Q per ACCEPTED flip (SURVEY.md 8d: 4n per proposal; a rejected "
+                                      "proposal needs no row with cached fields)"},
+            "fabric": fabric, "host_build_s": t_build, "upload_s": t_upload, "best_energy": float(en.min())}
 
 
 def main():
@@ -227,12 +328,12 @@ def main():
     t_up0 = time.perf_counter()
     if args.kernel == "dense":                                     # model resident in HBM before timing
         prob = Problem.dense(Qs, offset=0.0, device=local)
-        kernel_name, bytes_per_update = "k_anneal_dense_wg<44,4>", 4.0 * n
+        bytes_per_update = 4.0 * n
         layout = "dense fp32 Q 27.8 MB"
     else:
         prob = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                                 float(np.float32(m.c_pair)), device=local, order="slots")   # as the sampler does
-        kernel_name = "k_anneal_csr_rank1<16, true>"          # byte-state variant (n <= 9216)
+                                 float(np.float32(m.c_pair)), device=local, order="slots",
+                                 energy_model=(m.val, m.lin, m.c_pair))               # as the sampler does
         bytes_per_update = 8.0 * float(np.diff(m.rowptr).mean()) + 8.0      # deg_i*(4+4) + 8
         layout = "CSR (cut term) + uniform pair term, %.1f neighbours per cell on average" % float(np.diff(m.rowptr).mean())
 
@@ -266,20 +367,38 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    kernel_name = prob.kernel_name()                               # what the library launched for this model and R
     t_f0 = time.perf_counter()
-    _, en, info = prob.fetch()
+    states, en, info = prob.fetch()
     fetch_ms = (time.perf_counter() - t_f0) * 1e3                  # R x n state bytes + R energies -> host
     updates_per_step = world * R * len(betas) * n
     value = updates_per_step * args.steps / elapsed
     k_ms = float(np.mean(kernel_ms))                               # all launches of one step
     launch_ms = k_ms / launches                                    # = rocprofv3's average duration of the kernel
     sweeps_per_launch = len(betas) / launches
-    alg_bytes = bytes_per_update * R * sweeps_per_launch * n       # per launch (one GPU)
-    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+    alg_bytes = bytes_per_update * R * sweeps_per_launch * n       # per launch (one GPU): SURVEY 8d's per-update model
+    effective = alg_bytes / (launch_ms * 1e-3) / 1e9
+    accept = info["accepted"] / info["proposals"]
     if args.kernel == "dense":
+        # K1w: rows come out of the LDS ring / L2, only accepted flips need one: no memory roofline bounds it
+        # (LDS -> VGPR fill rate); the byte model is an effective figure only
         row_bytes = info["accepted"] * (((n + 255) // 256) * 256 * 4)   # padded rows the accepted flips consumed
+        roofline = {"bound": "lds_fill", "achieved": row_bytes / (k_ms * 1e-3) / 1e9, "peak": 157000.0, "unit": "GB/s",
+                    "frac": row_bytes / (k_ms * 1e-3) / 1e9 / 157000.0, "traffic": None,
+                    "model": "padded Q rows moved from LDS into registers by accepted flips; peak = 256 B/clk/CU x 256 CUs"}
     else:
-        row_bytes = R * len(betas) * ((n + 63) // 64) * 64 * (16 * 8 + 4 + 4 + 32)   # per slot: adjacency, lin, meta, 4 in-slot entries
+        ell_width = 16 if np.diff(m.rowptr).max() <= 16 else (32 if np.diff(m.rowptr).max() <= 32 else 64)
+        l2_bytes = l2_request_bytes_per_launch(kernel_name, R, sweeps_per_launch, n, ell_width)
+        l2_gbps = l2_bytes / (launch_ms * 1e-3) / 1e9
+        roofline = {"bound": "l2", "achieved": l2_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": l2_gbps / L2_PEAK_GBPS,
+                    "traffic": pmc_traffic(R, len(betas), launches, kernel_name),
+                    "l2_request_bytes_per_launch": l2_bytes,
+                    "model": "bytes the kernel's loads request from L2: per 64-variable slot the packed adjacency "
+                             "(%d x 64 x 8 B) + linear terms (256 B), once per wavefront (two replicas per wavefront in the "
+                             "pair kernel), every slot of every sweep; peak = L2 aggregate (MI355X_MICROARCH.md)" % ell_width,
+                    "binding_resource": binding_resource(kernel_name, R, len(betas))}
+    roofline.update({"kernel": kernel_name, "kernel_ms": launch_ms, "launches_per_step": launches,
+                     "sweeps_per_launch": sweeps_per_launch, "kernel_ms_per_step": k_ms, "acceptance": accept})
     best_state = best[3]
     cut_edges = int(np.sum(best_state[eu] != best_state[ev]))
     out = {
@@ -287,21 +406,16 @@ def main():
         "value": value, "unit": "spin-flip updates/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "PBMC3k-sized synthetic SNN (n=2638, k=5, dim=15, trim 15), clustering_bqm QUBO "
+        "config": {"workload": "PBMC3k-sized synthetic SNN (n=2638, k=5, dim=15, trim 15; 9 overlapping clusters, one connected "
+                               "component), clustering_bqm QUBO "
                                "(gamma_factor 0.05, k 8), %s, resident in HBM, %d replicas/GPU x %d sweeps, "
                                "geometric beta, seed 1234" % (layout, R, len(betas)),
                    "kernel": args.kernel,
                    "n": n, "replicas_per_gpu": R, "sweeps": int(len(betas)), "parallelism": "replicas sharded x%d" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(R, len(betas), launches, kernel_name),
-                     "kernel": kernel_name, "kernel_ms": launch_ms,
-                     "launches_per_step": launches, "sweeps_per_launch": sweeps_per_launch,
-                     "kernel_ms_per_step": k_ms,
-                     "algorithmic_bytes_per_update": bytes_per_update,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "binding_resource": binding_resource(kernel_name),
-                     "rows_GBps": row_bytes / (k_ms * 1e-3) / 1e9,
-                     "acceptance": info["accepted"] / info["proposals"]},
+        "roofline": roofline,
+        "effective": {"algorithmic_bytes_per_update": bytes_per_update, "algorithmic_bytes_per_launch": alg_bytes,
+                      "GBps": effective, "note": "SURVEY.md 8d byte model x updates / time: an effective-bandwidth figure "
+                      "(the model is cache resident and shared by the replicas), not a fraction of any peak"},
         "best_energy": float(m.energies(best_state[None, :])[0]),
         "mean_energy": float(np.mean(en)),
         "replicas_at_best_energy": int(np.sum(en <= en.min() + 1e-6 * abs(en.min()))),
@@ -315,7 +429,8 @@ def main():
         if world == 1:
             out["other_kernels"] = other_kernels(m, Qs, betas, graph, local, args.kernel)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(Qs, betas)
+            perm = prob.perm if prob.perm is not None else np.arange(n)
+            out["cpu_baseline"] = cpu_baseline(m, Qs, betas, (eu, ev), states, en, perm)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -134,6 +134,11 @@ int mi_sa_last_kernel_ms(mi_sa_problem *p, float *out_ms);
  * mi_sa_last_kernel_ms divided by this count is the average launch duration a profiler reports. */
 int mi_sa_last_launch_count(mi_sa_problem *p, int *out_launches);
 
+/* Name(s) of the kernel(s) those launches ran, as a profiler lists them (e.g. "k_anneal_csr_rank1_pair<16>";
+ * several joined by " + " when a chunked dense run alternates kernels).  The library picks the kernel from the
+ * model (kind, size, adjacency width, whether every slot is free of internal edges) and the number of replicas. */
+int mi_sa_last_kernel_name(mi_sa_problem *p, char *out, int len);
+
 /* Copy results of the last run to host: states (R x n, uint8 or uint16 by kind; nullable),
  * energies (R doubles, recomputed from the final state on device; nullable), stats (nullable):
  * stats[0] proposals, stats[1] accepted moves, stats[2] Q/CSR bytes read by accepted moves. */

@@ -1,24 +1,42 @@
 #!/usr/bin/env python3
-"""profiles/r01_i_pmc_k2/p*.csv (scripts/pmc_k2.sh) -> profiles/r01_k2_binding.json: the resource that binds the
-headline kernel, from rocprofv3 SQ counters.  VALU issue utilisation = SQ_INSTS_VALU x 4 cycles (a wave64
-instruction occupies its SIMD's VALU for 4 cycles) / (1024 SIMDs x kernel cycles); kernel cycles =
-GRBM_GUI_ACTIVE / 8 XCDs."""
-import csv, glob, json, os
+"""<dir>/p*.csv (scripts/pmc_k2.sh: separate rocprofv3 --pmc passes over the headline anneal kernel at the bench
+shape) -> profiles/r02_k2_binding.json: what the kernel uses of each resource that could bind it.
+  L2      TCC_REQ x 128 B per request / kernel time, against 34.5 TB/s (MI355X_MICROARCH.md, L2 aggregate)
+  LDS     SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles); share of it that is bank-conflict cycles
+  VALU    SQ_INSTS_VALU x c / (1024 SIMDs x kernel cycles) for c = 2 (SIMD-32 pass count of a wave64 op) and
+          c = 3.1 (measured issue cost of the VOP3 forms that dominate this kernel, scripts/ubench_valu.hip)
+  waves   SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY, SQ_WAIT_ANY as shares of SQ_WAVE_CYCLES
+kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs.   usage: k2_binding.py <dir> <replicas> <sweeps> [out.json]"""
+import csv, glob, json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-vals = {}
-for f in glob.glob(os.path.join(root, "profiles", "r01_i_pmc_k2", "p*.csv")):
+d, replicas, sweeps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+outp = sys.argv[4] if len(sys.argv) > 4 else os.path.join(root, "profiles", "r02_k2_binding.json")
+vals, kernel, dur = {}, None, []
+for f in sorted(glob.glob(os.path.join(d, "p*.csv"))):
     for r in csv.DictReader(open(f)):
         vals[r["Counter_Name"]] = float(r["Counter_Value"])
+        kernel = r["Kernel_Name"]
+        dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
+name = re.search(r"(k_\w+<[^>]*>)", kernel).group(1)
 cycles = vals["GRBM_GUI_ACTIVE"] / 8.0
-simd_cycles = 1024.0 * cycles
+ms = sorted(dur)[len(dur) // 2]
+l2_bytes = vals["TCC_REQ_sum"] * 128.0
 out = {
-    "kernel": "k_anneal_csr_rank1<16, *>", "workload": "4096 replicas x 200 sweeps, n = 2638 (scripts/perf_k2.py --order slots)",
-    "resource": "VALU instruction issue", "utilisation": vals["SQ_INSTS_VALU"] * 4.0 / simd_cycles,
-    "salu_issue_utilisation": vals["SQ_INSTS_SALU"] * 4.0 / simd_cycles,
-    "valu_wave_instructions": vals["SQ_INSTS_VALU"], "salu_wave_instructions": vals["SQ_INSTS_SALU"],
-    "lds_instructions": vals["SQ_INSTS_LDS"], "vmem_read_instructions": vals["SQ_INSTS_VMEM_RD"],
-    "l2_hit_rate": vals["TCC_HIT_sum"] / vals["TCC_REQ_sum"], "kernel_cycles": cycles,
-    "source": "profiles/r01_i_pmc_k2/p1..p5.csv",
+    "kernel": name, "replicas": replicas, "sweeps": sweeps,
+    "kernel_ms_profiled": ms, "kernel_cycles": cycles, "clock_GHz": cycles / (ms * 1e6),
+    "l2": {"request_bytes": l2_bytes, "GBps": l2_bytes / (ms * 1e-3) / 1e9, "peak_GBps": 34500.0,
+           "frac": l2_bytes / (ms * 1e-3) / 1e9 / 34500.0, "hit_rate": vals["TCC_HIT_sum"] / vals["TCC_REQ_sum"]},
+    "lds": {"busy_frac": vals["SQ_LDS_IDX_ACTIVE"] / (256.0 * cycles),
+            "bank_conflict_share": vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]},
+    "valu": {"wave_instructions": vals["SQ_INSTS_VALU"],
+             "issue_frac_at_2_cycles": vals["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles),
+             "issue_frac_at_3p1_cycles": vals["SQ_INSTS_VALU"] * 3.1 / (1024.0 * cycles)},
+    "salu_wave_instructions": vals["SQ_INSTS_SALU"], "lds_instructions": vals["SQ_INSTS_LDS"],
+    "vmem_read_instructions": vals["SQ_INSTS_VMEM_RD"],
+    "waves": {"active_issuing": vals["SQ_ACTIVE_INST_ANY"] / vals["SQ_WAVE_CYCLES"],
+              "stalled_on_issue": vals["SQ_WAIT_INST_ANY"] / vals["SQ_WAVE_CYCLES"],
+              "parked_on_waitcnt": vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"]},
+    "source": "%s/p1..p6.csv (scripts/pmc_k2.sh)" % os.path.relpath(d, root),
 }
-json.dump(out, open(os.path.join(root, "profiles", "r01_k2_binding.json"), "w"), indent=1)
-print(out)
+json.dump(out, open(outp, "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -5,6 +5,7 @@ set -u
 out=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc_bench}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+export MI_BENCH_SKIP_50K=1      # the 10 GB dense side run has its own passes (scripts/pmc_dense50k.sh)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/trace.log 2>&1
 for f in $(find $out/trace -name '*kernel_stats.csv'); do cp $f $out/kernel_stats.csv; done
 for c in FETCH_SIZE WRITE_SIZE; do

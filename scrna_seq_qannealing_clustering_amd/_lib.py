@@ -53,6 +53,7 @@ def _declare(lib):
         "mi_sa_sync": (C.c_int, [vp]),
         "mi_sa_last_kernel_ms": (C.c_int, [vp, f32p]),
         "mi_sa_last_launch_count": (C.c_int, [vp, ip]),
+        "mi_sa_last_kernel_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "mi_sa_fetch": (C.c_int, [vp, vp, f64p, u64p]),
         "mi_sa_best": (C.c_int, [vp, ip, f64p, u64p, vp]),
         "mi_sa_qubo_dense_f32": (C.c_int, [f32p, C.c_int, C.c_double, C.c_int, C.c_int, f64p,
@@ -82,7 +83,7 @@ EXPORTS = (
     "mi_last_error", "mi_abi_version", "mi_device_count", "mi_device_info",
     "mi_sa_problem_create_dense_f32", "mi_sa_problem_create_csr_rank1_f32",
     "mi_sa_problem_create_potts_csr_f32", "mi_sa_problem_destroy", "mi_sa_problem_info",
-    "mi_sa_set_option", "mi_sa_problem_set_energy_model_f64", "mi_sa_debug_pace", "mi_sa_debug_stats", "mi_sa_anneal", "mi_sa_anneal_ex", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_last_launch_count", "mi_sa_fetch", "mi_sa_best",
+    "mi_sa_set_option", "mi_sa_problem_set_energy_model_f64", "mi_sa_debug_pace", "mi_sa_debug_stats", "mi_sa_anneal", "mi_sa_anneal_ex", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_last_launch_count", "mi_sa_last_kernel_name", "mi_sa_fetch", "mi_sa_best",
     "mi_sa_qubo_dense_f32", "mi_energy_dense_f32", "mi_energy_dense_f64", "mi_energy_dense_f32_ex",
     "mi_snn_build_f32", "mi_snn_info", "mi_snn_fetch", "mi_snn_kernel_ms", "mi_snn_destroy",
     "mi_jaccard_cluster_stats",

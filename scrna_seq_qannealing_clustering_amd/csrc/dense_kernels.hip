@@ -486,6 +486,7 @@ int launch_dense(const DenseLaunchCtx &p, DenseArgs a, hipStream_t st)
     const uint8_t *init0 = a.init;
     uint8_t *states0 = a.states;
     double *energy0 = a.energy;
+    const float *temps0 = a.temps;
     int chunk = (*p.resident_waves);
     if ((total + chunk - 1) / chunk > kMaxChunks) chunk = (total + kMaxChunks - 1) / kMaxChunks;
     const bool pace = p.opt_pace && a.num_sweeps > 1;
@@ -499,7 +500,9 @@ int launch_dense(const DenseLaunchCtx &p, DenseArgs a, hipStream_t st)
         a.init = init0 ? init0 + (size_t)lo * a.n : nullptr;
         a.states = states0 + (size_t)lo * a.n;
         a.energy = energy0 + lo;
+        a.temps = temps0 + (a.temps_per_replica ? lo : 0);          // one temperature per replica: the chunk's own
         a.pace = (pace && cnt <= (*p.resident_waves)) ? p.d_pace + (size_t)c * kPaceWords : nullptr;
+        note_kernel("k_anneal_dense<%d>", NT);
         hipLaunchKernelGGL(k_anneal_dense<NT>, dim3((cnt + 3) / 4), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
     }
@@ -520,6 +523,7 @@ int launch_dense_wg(const DenseLaunchCtx &p, DenseArgs a, hipStream_t st)
             HIP_TRY(hipMemsetAsync(p.d_pace, 0, kPaceWords * sizeof(unsigned int), st));
             a.pace = p.d_pace;
         }
+        note_kernel("k_anneal_dense_wg<%d,%d>", NT, GR);
         hipLaunchKernelGGL((k_anneal_dense_wg<NT, GR>), dim3((a.R + kWgWaves - 1) / kWgWaves), dim3(1024), 0, st, a);
         HIP_TRY(hipGetLastError());
         return MI_OK;

@@ -321,6 +321,7 @@ int MI_CAT(mi_launch_dense_mfma_nt, MI_NT)(const DenseArgs &a, hipStream_t st)
 {
     if constexpr (MfCfg<MI_NT>::ok) {
         if (!a.Qm) return fail(MI_EINVAL, "K1m needs the row-major matrix copy");
+        note_kernel("k_anneal_dense_mfma<%d>", MI_NT);
         hipLaunchKernelGGL((k_anneal_dense_mfma<MI_NT>), dim3((a.R + 15) / 16), dim3(1024), 0, st, a);
         HIP_TRY(hipGetLastError());
         return MI_OK;

@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(kXlThreads) k_anneal_dense_xl(DenseXlArgs a)
 template <int CH>
 int launch_xl(const DenseXlArgs &a, hipStream_t st)
 {
+    note_kernel("k_anneal_dense_xl<%d>", CH);
     hipLaunchKernelGGL((k_anneal_dense_xl<CH>), dim3(a.R), dim3(kXlThreads), 0, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;

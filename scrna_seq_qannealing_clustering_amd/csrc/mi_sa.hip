@@ -37,6 +37,18 @@ namespace mi_sa_impl {
 // ------------------------------------------------------------------------------------------------
 thread_local std::string g_err;
 
+thread_local std::string g_kernel;
+
+void note_kernel(const char *fmt, ...)
+{
+    char buf[128];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g_kernel.find(buf) == std::string::npos) g_kernel += (g_kernel.empty() ? "" : " + ") + std::string(buf);
+}
+
 int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -138,6 +150,7 @@ struct mi_sa_problem {
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
     int last_launches = 1;                   // kernel launches that served the last anneal
+    std::string last_kernel;                 // ... and the kernel(s) they ran
     size_t state_elem = 1;
 };
 
@@ -604,6 +617,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         HIP_TRY(hipMemcpyAsync(p->d_init, init, (size_t)R * p->n * p->state_elem, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_stats, 0, 16 * sizeof(unsigned long long), p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));   // inputs resident before the timed region
+    g_kernel.clear();
 
     if (p->kind == MI_KIND_DENSE && p->xl_chunks > 0) {
         DenseXlArgs a;
@@ -660,6 +674,7 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
     }
     p->last_R = R; p->last_offset = replica_offset; p->has_run = true;
+    p->last_kernel = g_kernel;
     return MI_OK;
 }
 
@@ -692,6 +707,14 @@ int mi_sa_last_launch_count(mi_sa_problem *p, int *out_launches)
     if (!p || !out_launches) return fail(MI_EINVAL, "NULL argument");
     if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
     *out_launches = p->last_launches;
+    return MI_OK;
+}
+
+int mi_sa_last_kernel_name(mi_sa_problem *p, char *out, int len)
+{
+    if (!p || !out || len < 1) return fail(MI_EINVAL, "NULL argument");
+    if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
+    snprintf(out, (size_t)len, "%s", p->last_kernel.c_str());
     return MI_OK;
 }
 

@@ -12,6 +12,7 @@
 namespace mi_sa_impl {
 
 int fail(int code, const char *fmt, ...);
+void note_kernel(const char *fmt, ...);      // the launchers record which kernel serves the running anneal (mi_sa_last_kernel_name)
 
 #define HIP_TRY(expr)                                                                            \
     do {                                                                                         \

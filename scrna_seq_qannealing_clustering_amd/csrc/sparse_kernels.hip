@@ -693,6 +693,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
 template <typename KernelT>
 int launch_sparse(KernelT kernel, const EllArgs &a, size_t lds_per_wave, hipStream_t st)
 {
+    note_kernel("k_anneal_potts<%d>", a.D <= 64 ? a.D : 0);
     int waves = kSparseWaves;                    // fewer replicas per workgroup when their LDS state is large
     while (waves > 1 && lds_per_wave * waves > 160 * 1024) --waves;
     const size_t lds = lds_per_wave * waves;
@@ -712,6 +713,7 @@ int launch_csr_rank1(KernelT kernel, const EllArgs &a, size_t lds, hipStream_t s
     if (!a.adj4 || !a.slot_flags) return fail(MI_EHIP, "csr_rank1: packed adjacency missing");
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    note_kernel("k_anneal_csr_rank1<%d, %d>", a.D <= 64 ? a.D : 0, a.state_bytes);
     hipLaunchKernelGGL(kernel, dim3(a.R), dim3(64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;

@@ -217,6 +217,7 @@ int launch_pair(KernelT kernel, const EllArgs &a, hipStream_t st)
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1 pair kernel: n = %d exceeds the state LDS budget", a.n);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    note_kernel("k_anneal_csr_rank1_pair<%d>", a.D);
     hipLaunchKernelGGL(kernel, dim3((a.R + 1) / 2), dim3(64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;

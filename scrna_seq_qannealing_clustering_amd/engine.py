@@ -198,6 +198,12 @@ class Problem:
         _lib.check(_lib.load().mi_sa_last_launch_count(self._h, C.byref(k)))
         return int(k.value)
 
+    def kernel_name(self) -> str:
+        """The kernel(s) that served the last anneal, as a profiler names them."""
+        buf = C.create_string_buffer(256)
+        _lib.check(_lib.load().mi_sa_last_kernel_name(self._h, buf, 256))
+        return buf.value.decode()
+
     def fetch(self, states: bool = True, energies: bool = True):
         if self._last is None:
             raise RuntimeError("fetch() before anneal()")
