@@ -342,7 +342,7 @@ def main():
     def step(i):
         prob.anneal(R, betas, SEED + i, replica_offset=rank * R)
         idx, e, key, state = prob.best()                           # K5 on device; waits for the anneal
-        return D.global_best(key, state)                           # C1 + C2 (identity at N=1)
+        return D.global_best(key, state, num_reads=world * R)      # C1 + C2 (identity at N=1)
 
     def fence():
         torch.cuda.synchronize()

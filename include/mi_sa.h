@@ -144,9 +144,11 @@ int mi_sa_last_kernel_name(mi_sa_problem *p, char *out, int len);
  * stats[0] proposals, stats[1] accepted moves, stats[2] Q/CSR bytes read by accepted moves. */
 int mi_sa_fetch(mi_sa_problem *p, void *out_states, double *out_energy, uint64_t *out_stats);
 
-/* Best replica of the last run (reduced on device): its local index, energy, and an order-preserving
- * packed key  (sortable(float(E)) << 32) | global_replica_id  suitable for an integer MIN all-reduce
- * across GPUs (RCCL has no MINLOC).  out_state (nullable) receives that replica's n states. */
+/* Best replica of the last run (reduced on device): the replica with the lowest fp64 energy (ties: the lowest
+ * index) -- its local index, energy, and an order-preserving packed key
+ * (sortable(float(E)) << 32) | global_replica_id  suitable for an integer MIN all-reduce across GPUs (RCCL has
+ * no MINLOC; between GPUs the comparison therefore has fp32 resolution of E).  out_state (nullable) receives
+ * that replica's n states. */
 int mi_sa_best(mi_sa_problem *p, int *out_index, double *out_energy, uint64_t *out_key,
                void *out_state);
 

@@ -71,23 +71,36 @@ __device__ __forceinline__ uint32_t sortable_f32(float v)
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-__global__ void __launch_bounds__(256) k_best(const double *__restrict__ energy, int R,
-                                              uint32_t replica_offset,
-                                              unsigned long long *__restrict__ out_key)
+// One workgroup: the replica with the lowest fp64 energy (ties: the lowest index) -- exactly the record a sorted
+// SampleSet puts first.  The packed key it writes for the cross-GPU exchange carries float(E): between GPUs the
+// comparison has fp32 resolution (1 part in 1.7e7 of |E|), inside one GPU it is exact.
+__global__ void __launch_bounds__(1024) k_best(const double *__restrict__ energy, int R,
+                                               uint32_t replica_offset,
+                                               unsigned long long *__restrict__ out_key)
 {
-    unsigned long long best = ~0ull;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-        const unsigned long long key =
-            ((unsigned long long)sortable_f32((float)energy[r]) << 32) |
-            (unsigned long long)(replica_offset + (uint32_t)r);
-        best = key < best ? key : best;
+    __shared__ double s_e[16];
+    __shared__ int s_i[16];
+    double be = INFINITY;
+    int bi = 0x7fffffff;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const double e = energy[r];
+        if (e < be || (e == be && r < bi)) { be = e; bi = r; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off, 64);
-        best = o < best ? o : best;
+        const double oe = __shfl_xor(be, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
     }
-    if ((threadIdx.x & 63) == 0) atomicMin(out_key, best);
+    if ((threadIdx.x & 63) == 0) { s_e[threadIdx.x >> 6] = be; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (s_e[w] < be || (s_e[w] == be && s_i[w] < bi)) { be = s_e[w]; bi = s_i[w]; }
+        if (bi == 0x7fffffff) bi = 0;                       // every energy NaN: report replica 0
+        out_key[0] = ((unsigned long long)sortable_f32((float)energy[bi]) << 32) |
+                     (unsigned long long)(replica_offset + (uint32_t)bi);
+    }
 }
 
 }  // namespace mi_sa_impl
@@ -743,8 +756,7 @@ int mi_sa_best(mi_sa_problem *p, int *out_index, double *out_energy, uint64_t *o
     HIP_TRY(hipSetDevice(p->device));
     unsigned long long init_key = ~0ull, key = 0;
     HIP_TRY(hipMemcpyAsync(p->d_stats + 3, &init_key, sizeof init_key, hipMemcpyHostToDevice, p->stream));
-    const int blocks = (p->last_R + 255) / 256 < 1024 ? (p->last_R + 255) / 256 : 1024;
-    hipLaunchKernelGGL(k_best, dim3(blocks), dim3(256), 0, p->stream, p->d_energy, p->last_R, p->last_offset, p->d_stats + 3);
+    hipLaunchKernelGGL(k_best, dim3(1), dim3(1024), 0, p->stream, p->d_energy, p->last_R, p->last_offset, p->d_stats + 3);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&key, p->d_stats + 3, sizeof key, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));

@@ -8,16 +8,24 @@ on ``G``.  The only exchange is at the end:
 
   (C1) all-reduce(MIN) of one packed 64-bit key per rank  ``(sortable(float E_best) << 32) | global id``
        -- RCCL has no MINLOC, the packing makes an integer MIN do it (8 bytes per GPU over xGMI);
-  (C2) broadcast of the winner's n labels from its owner rank.
+  (C2) broadcast of the winner's n labels (n bytes) from its owner rank.  The owner needs no second
+       collective: replicas are sharded contiguously (``shard_range``), so the winning global id names its rank.
 
 ``torch.distributed`` is the transport (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+
+``HSA_ENABLE_IPC_MODE_LEGACY=0`` (dmabuf IPC: what RCCL needs on this driver) only takes effect when it is in
+the environment BEFORE the process makes its first HIP call, so it is set here at import time; a launcher
+that touches the GPU before importing this module has to export it itself.
 """
 from __future__ import annotations
 
 import os
-from typing import Optional, Tuple
 
-import numpy as np
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from typing import Optional, Tuple      # noqa: E402
+
+import numpy as np                      # noqa: E402
 
 _SIGN = 1 << 63
 
@@ -60,7 +68,6 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL on this driver)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -72,31 +79,49 @@ def shard_range(num_reads: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def global_best(local_key: int, local_state: np.ndarray, group=None, device=None):
+def owner_of(global_id: int, num_reads: int, world: int, base: int = 0) -> int:
+    """Rank that ran global replica ``global_id`` when ``num_reads`` replicas with ids ``base ..`` were sharded by
+    ``shard_range`` (remainders to the low ranks)."""
+    g = int(global_id) - int(base)
+    q, rem = divmod(int(num_reads), int(world))
+    if g < 0 or g >= num_reads:
+        raise ValueError("replica id %d is outside the run [%d, %d)" % (global_id, base, base + num_reads))
+    if q == 0:
+        return g
+    cut = rem * (q + 1)                         # the first `rem` ranks hold q + 1 replicas each
+    return g // (q + 1) if g < cut else rem + (g - cut) // q
+
+
+def global_best(local_key: int, local_state: np.ndarray, group=None, device=None,
+                num_reads: Optional[int] = None, base: int = 0):
     """C1 + C2.  ``local_key`` = this rank's packed best key (``Problem.best()[2]``), ``local_state``
-    its n labels.  Returns ``(energy_f32, global_replica_id, owner_rank, state)`` identical on every
-    rank.  Without an initialised process group it is the identity."""
+    its n labels.  ``num_reads`` = replicas over ALL ranks, ``base`` = the first global id of the run (the
+    winner's rank follows from its id and the contiguous sharding, ``owner_of``).  Returns
+    ``(energy_f32, global_replica_id, owner_rank, state)`` identical on every rank.  Without an initialised
+    process group it is the identity.  ONE 8-byte MIN all-reduce and ONE n-byte broadcast."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         e, gid = unpack_key(local_key)
         return e, gid, 0, np.asarray(local_state).copy()
-    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
     if device is None:
         device = (torch.device("cuda", torch.cuda.current_device())
                   if dist.get_backend(group) == "nccl" else torch.device("cpu"))
     k = torch.tensor([_to_signed(local_key)], dtype=torch.int64, device=device)
     dist.all_reduce(k, op=dist.ReduceOp.MIN, group=group)                      # (C1)
     best = _from_signed(int(k.item()))
-    # owner = the rank whose own key won (ids are unique, so exactly one rank matches)
-    mine = torch.tensor([rank if best == local_key else -1], dtype=torch.int64, device=device)
-    dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=group)
-    owner = int(mine.item())
-    st = torch.from_numpy(np.ascontiguousarray(local_state).astype(np.int32)).to(device)
+    e, gid = unpack_key(best)
+    if num_reads is None:
+        raise ValueError("global_best needs num_reads (replicas over all ranks) to name the winner's rank")
+    owner = owner_of(gid, num_reads, world, base)
+    local_state = np.ascontiguousarray(local_state)
+    # labels travel as they are stored: one byte per variable for binary states, two for Potts labels
+    # (viewed as bytes: RCCL reduces no uint16)
+    st = torch.from_numpy(local_state.view(np.uint8).copy()).to(device)
     dist.broadcast(st, src=dist.get_global_rank(group, owner) if group is not None else owner,
                    group=group)                                                 # (C2)
-    e, gid = unpack_key(best)
-    return e, gid, owner, st.cpu().numpy().astype(np.asarray(local_state).dtype)
+    return e, gid, owner, st.cpu().numpy().view(local_state.dtype)
 
 
 def gather_energies(local_energy: np.ndarray, group=None, device=None) -> np.ndarray:

@@ -40,6 +40,18 @@ def test_shard_range_covers_everything():
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
 
 
+def test_owner_follows_from_the_global_id():
+    """The winner's rank is derived from its global replica id (no second collective): equal to a search over
+    shard_range for even, uneven and more-ranks-than-replicas shardings, with and without a base offset."""
+    for R, W, base in [(4096, 8, 0), (10, 3, 0), (11, 2, 100), (2, 4, 0), (7, 1, 5), (32768, 8, 4096), (13, 5, 0)]:
+        spans = [D.shard_range(R, r, W) for r in range(W)]
+        for g in range(R):
+            want = next(r for r, (lo, hi) in enumerate(spans) if lo <= g < hi)
+            assert D.owner_of(base + g, R, W, base) == want
+        with pytest.raises(ValueError):
+            D.owner_of(base + R, R, W, base)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -61,7 +73,7 @@ def _worker(rank, world, port, R, out_dir):
     st, en, _ = so.sa_dense_philox(Qs, hi - lo, betas, 99, replica_offset=lo)     # this rank's shard
     k = int(np.argmin(en.astype(np.float32)))
     key = D.pack_key(float(en[k]), lo + k)
-    e, gid, owner, state = D.global_best(key, st[k])
+    e, gid, owner, state = D.global_best(key, st[k], num_reads=R)
     allen = D.gather_energies(en)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), e=e, gid=gid, owner=owner, state=state, allen=allen,
              lo=lo, hi=hi)
@@ -73,7 +85,7 @@ def _worker(rank, world, port, R, out_dir):
 def test_two_rank_gloo_global_best_matches_single_process(tmp_path):
     import torch.multiprocessing as mp
     from oracle import sa_oracle as so
-    R, world = 10, 2                                           # uneven-free but small; ranks get 5 + 5
+    R, world = 11, 2                                           # uneven shards: ranks get 6 + 5
     mp.spawn(_worker, args=(world, _free_port(), R, str(tmp_path)), nprocs=world, join=True)
     fx = load_fixture("noisy_moons")
     m = models.build_bqm_qubo(fx.graph(), 0.05)
@@ -85,7 +97,7 @@ def test_two_rank_gloo_global_best_matches_single_process(tmp_path):
     for o in outs:
         assert int(o["gid"]) == best                            # global replica id of the winner
         assert float(o["e"]) == float(np.float32(en[best]))
-        assert int(o["owner"]) == (0 if best < 5 else 1)
+        assert int(o["owner"]) == (0 if best < 6 else 1)
         assert np.array_equal(o["state"], st[best])             # winner's labels on every rank
         assert np.array_equal(o["allen"], en)                   # all-gather in global replica order
     assert np.array_equal(outs[0]["state"], outs[1]["state"])

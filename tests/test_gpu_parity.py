@@ -317,6 +317,40 @@ def test_dense_beyond_4096_variables_workgroup_per_replica(n, R, sweeps):
         assert np.allclose(en, oen, rtol=1e-5, atol=1e-3)
 
 
+def test_full_size_properties_config4_dense_50k():
+    """BASELINE config 4 in its stated form: a 50 000-cell synthetic SNN graph (built on the GPU by snn.build_snn),
+    the clustering_bqm QUBO as a DENSE fp32 matrix resident in HBM (10.6 GB), K1x.  Two replicas x two sweeps at
+    temperatures from the middle of the schedule against the oracle's dense chain: states, accepted counts, energies
+    (from the cached fp32 fields: 1e-3 at this size), and the integer edge cut of both."""
+    from scrna_seq_qannealing_clustering_amd import snn
+    n = 50000
+    rng = np.random.RandomState(1)
+    centers = rng.normal(scale=4.0, size=(30, 15))
+    X = (centers[rng.randint(0, 30, size=n)] + rng.normal(size=(n, 15))).astype(np.float32)
+    g = snn.build_snn(X, 5, 0.0, 15)
+    nodes, eu, ev, w = g.edge_list()
+    m = models.build_bqm_qubo(g.to_graph(), 0.05)
+    Qs = np.full((n, n), np.float32(m.c_pair / 2.0), dtype=np.float32)          # Qs_ij = (c_pair + S_ij) / 2
+    rows = np.repeat(np.arange(n), np.diff(m.rowptr))
+    Qs[rows, m.col] += (m.val / 2.0).astype(np.float32)
+    Qs[np.arange(n), np.arange(n)] = m.lin.astype(np.float32)
+    betas = models.make_beta_schedule(1000, models.default_beta_range(m))[620:622]
+    with Problem.dense(Qs) as p:
+        p.anneal(2, betas, 77, replica_offset=4094)
+        st, en, info = p.fetch()
+        assert p.kernel_name().startswith("k_anneal_dense_xl<13>")
+    ost, oen, ostats = so.sa_dense_philox(Qs, 2, betas, 77, replica_offset=4094)
+    del Qs
+    assert info["proposals"] == 2 * 2 * n and info["accepted"] == int(ostats[1]) and info["accepted"] > 100
+    assert np.array_equal(st, ost)
+    # K1x reports the energy its cached fp32 fields imply (no second pass over 5 GB of rows per replica): 25 000
+    # fields of magnitude ~1e3 each carry fp32 rounding, 1e-3 relative at this size; the oracle's is an fp64
+    # re-evaluation, equal to the caller's model to fp32 storage of Q
+    assert np.allclose(en, oen, rtol=1e-3)
+    assert np.allclose(oen, m.energies(st), rtol=1e-6)
+    assert np.array_equal(so.cut_edges(eu, ev, st), so.cut_edges(eu, ev, ost))
+
+
 def test_energy_kernel_fp64_matrix():
     """mi_energy_dense_f64: the caller-model energies of a dense problem's samples, against numpy fp64."""
     from scrna_seq_qannealing_clustering_amd.engine import energy_dense_f64
