@@ -97,6 +97,14 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value);
 /* Diagnostic: copies the first `words` pacing words of the last launch (layout in mi_sa.hip). */
 int mi_sa_debug_pace(mi_sa_problem *p, unsigned int *out, int words);
 
+/* Host-only planning (touches no device): the sweep order the structured kernels run fastest in.  Renumbers the
+ * variables of a symmetric CSR graph so that the `slot` (= 64, the wavefront width) variables a wavefront sweeps
+ * together are, as far as a degree-descending greedy balanced colouring manages, mutually NON-adjacent; inside
+ * such a block the decisions of a sweep interact only through sum(x).  out_perm[new] = old.  Any visiting order
+ * is a valid Metropolis sweep; the caller renumbers the model with it before mi_sa_problem_create_* and maps the
+ * states back (scrna_seq_qannealing_clustering_amd/engine.py does).  Identity for n > 262144. */
+int mi_sa_plan_slot_order(const int32_t *rowptr, const int32_t *col, int n, int slot, int64_t *out_perm);
+
 /* Diagnostic: copies the first `words` (<= 16) 64-bit statistics words of the last run ([0..2] as in
  * mi_sa_fetch; [8..12] per-phase cycle sums of builds compiled with -DMI_K2_PROFILE, otherwise 0). */
 int mi_sa_debug_stats(mi_sa_problem *p, uint64_t *out, int words);
@@ -119,9 +127,26 @@ int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweep
  *                         num_sweeps sweeps of this call (one rung of a tempering ladder per replica). */
 #define MI_F_CONTINUE         1u
 #define MI_F_BETA_PER_REPLICA 2u
+#define MI_F_TEMPS_RESIDENT   4u   /* betas ignored (may be NULL): every replica anneals at the temperature the
+                                    * tempering state on the device holds for it (mi_sa_tempering_begin / _exchange) */
 int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
                     const double *betas, uint64_t seed, const void *init, int resync_interval,
                     uint32_t sweep_offset, uint32_t flags);
+
+/* ---- parallel tempering: the replica-exchange step on the device (K6) --------------------------
+ * A run has T x chains replicas; global replica g belongs to chain g / T and starts on ladder rung g % T.  This GPU
+ * owns the R_local replicas first_replica .. (contiguous shard).  A round = mi_sa_anneal_ex(R_local, first_replica,
+ * sweeps, NULL, seed, NULL, 0, round * sweeps, MI_F_TEMPS_RESIDENT | MI_F_CONTINUE (after the first round)), then
+ * mi_sa_tempering_exchange(round, seed, all_energies): neighbouring rungs of each chain exchange with the Metropolis
+ * rule on a counter-based random stream of (seed, round), rung INDICES move, states stay where they are.
+ *   all_energies = NULL    one GPU owns every replica: the energies never leave HBM, nothing is copied either way;
+ *   all_energies = host array of all T x chains energies in global order (the all-gather of the ranks' energies):
+ *                          every rank runs the same exchange and gets the same rungs.
+ * mi_sa_tempering_state copies the rung of every replica and the proposed / accepted exchange counts. */
+int mi_sa_tempering_begin(mi_sa_problem *p, const double *ladder_betas, int T, int chains,
+                          uint32_t first_replica, int R_local);
+int mi_sa_tempering_exchange(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *all_energies);
+int mi_sa_tempering_state(mi_sa_problem *p, int32_t *out_rung, uint64_t *out_proposed, uint64_t *out_accepted);
 
 int mi_sa_sync(mi_sa_problem *p);
 

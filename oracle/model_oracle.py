@@ -119,3 +119,31 @@ def dqm_energy(linear, quadratic, labels):
 
 def cut_edges(edges, sample):
     return sum(1 for u, v, _ in edges if sample[u] != sample[v])
+
+
+def slot_independent_order(rowptr, col, slot=64):
+    """Restatement of the sweep-ordering pass of the native library (mi_sa_plan_slot_order): degree-descending
+    greedy, each variable into the least-filled block that holds none of its neighbours (ties: lowest block), a
+    block that does only as a last resort; blocks emitted in order, variables inside a block by original index."""
+    import numpy as np
+    rowptr = np.asarray(rowptr)
+    col = np.asarray(col)
+    n = len(rowptr) - 1
+    nslots = (n + slot - 1) // slot
+    if nslots <= 1 or n > (1 << 18):
+        return np.arange(n, dtype=np.int64)
+    cap = np.full(nslots, slot, dtype=np.int64)
+    cap[-1] = n - slot * (nslots - 1)
+    fill = np.zeros(nslots, dtype=np.int64)
+    where = np.full(n, -1, dtype=np.int64)
+    deg = np.diff(rowptr)
+    big = np.int64(1) << 40
+    for v in np.argsort(-deg, kind="stable"):
+        key = fill * nslots + np.arange(nslots)              # least filled first, ties by slot index
+        key = np.where(fill >= cap, 4 * big, key)            # full slots are never chosen
+        nb = where[col[rowptr[v]:rowptr[v + 1]]]
+        key[nb[nb >= 0]] += big                              # slots holding a neighbour: only as a last resort
+        s = int(np.argmin(key))
+        where[v] = s
+        fill[s] += 1
+    return np.lexsort((np.arange(n), where)).astype(np.int64)

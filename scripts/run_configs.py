@@ -72,10 +72,11 @@ S = 20 if a.quick else 200
 with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(f32), m.lin.astype(f32), float(f32(m.c_pair)), order="slots") as p:
     p.anneal(1024, models.make_beta_schedule(S, models.default_beta_range(m)), 1234)
     ms = p.kernel_ms()
+    p_kernel4 = p.kernel_name()
     st, en, info = p.fetch()
 best = st[int(np.argmin(en))]
 out["config4_bqm_n50000"] = {
-    "kernel": "k_anneal_csr_rank1<16>", "replicas": 1024, "sweeps": S, "kernel_ms": ms,
+    "kernel": p_kernel4, "replicas": 1024, "sweeps": S, "kernel_ms": ms,
     "updates_per_s": 1024 * S * n4 / (ms * 1e-3), "acceptance": info["accepted"] / info["proposals"],
     "best_energy": float(m.energies(best[None, :])[0]), "best_split": [int(best.sum()), int(n4 - best.sum())],
     "edges": int(len(g.col) // 2), "snn_build_ms": g.timing, "snn_build_wall_s": t_build,
@@ -104,11 +105,20 @@ class TimedEngine(tempering.ProblemEngine):
 
 
 res = tempering.parallel_tempering(TimedEngine(prob, 1234), ladder, chains, rounds, sweeps_per_round, 1234)
+wall_timed = time.perf_counter() - t0
+# the same run as the product runs it: exchange on the device, no per-round read of anything (history off) --
+# the wall time of the whole tempering against the sum of its anneal kernels
+t0 = time.perf_counter()
+res2 = tempering.parallel_tempering(tempering.ProblemEngine(prob, 1234), ladder, chains, rounds, sweeps_per_round, 1234,
+                                    history=False)
 wall = time.perf_counter() - t0
+assert np.array_equal(res2["rung"], res["rung"]) and np.array_equal(res2["energies"], res["energies"])
 lab = res["local_states"]
+pt_kernel = prob.kernel_name()
 prob.close()
 out["config5_dqm_k15_n10605_tempering"] = {
-    "kernel": "k_anneal_potts<16>", "rungs": rungs, "chains_per_rung": chains, "rounds": rounds,
+    "kernel": pt_kernel + " + k_pt_exchange", "wall_s_with_per_round_timing_and_history": wall_timed,
+    "wall_over_kernel": wall / (kernel_ms[0] * 1e-3), "rungs": rungs, "chains_per_rung": chains, "rounds": rounds,
     "sweeps_per_round": sweeps_per_round, "kernel_ms": kernel_ms[0], "wall_s": wall,
     "updates_per_s": rungs * chains * rounds * sweeps_per_round * n5 / (kernel_ms[0] * 1e-3),
     "best_energy": res["best_energy"], "purity_of_best": purity(lab[res["best_replica"]], truth),
@@ -118,4 +128,4 @@ print(json.dumps(out["config5_dqm_k15_n10605_tempering"]), flush=True)
 
 for folder in ("profiles", "gpurun_out"):            # gpurun_out/ is what travels back from the GPU box
     os.makedirs(os.path.join(ROOT, folder), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, folder, "r01_configs.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, folder, "r02_configs.json"), "w"), indent=1)

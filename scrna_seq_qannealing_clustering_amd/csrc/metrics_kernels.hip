@@ -173,7 +173,7 @@ extern "C" int mi_jaccard_cluster_stats(const uint64_t *bits, int n, int words, 
     const size_t per_plane = (size_t)n * K + 2 * (size_t)n;                   // rowsum, rowsq_all, rowsq_within
     float *d_D = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = [&]() -> int {
+    int rc = guarded([&]() -> int {
         HIP_TRY(hipMalloc((void **)&d_bits, (size_t)n * words * 8));
         HIP_TRY(hipMalloc((void **)&d_lab, (size_t)n * 4));
         HIP_TRY(hipMalloc((void **)&d_rowsum, (size_t)n * K * 8));
@@ -227,7 +227,7 @@ extern "C" int mi_jaccard_cluster_stats(const uint64_t *bits, int n, int words, 
         for (int c = 0; c < K; ++c) separation[c * K + c] = 0.0;
         if (out_D) HIP_TRY(hipMemcpy(out_D, d_D, (size_t)n * n * 4, hipMemcpyDeviceToHost));
         return MI_OK;
-    }();
+    });
     void *bufs[] = {d_orig, d_bits, d_lab, d_rowsum, d_sqa, d_sqw, d_part, d_diam, d_sep, d_D};
     for (void *b : bufs)
         if (b) (void)hipFree(b);

@@ -14,6 +14,7 @@
 //
 // Reference call sites served: BQM_clustering.py:57,75,85,245,263,273,386 ; DQM_clustering.py:45.
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -103,6 +104,49 @@ __global__ void __launch_bounds__(1024) k_best(const double *__restrict__ energy
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K6: replica exchange of parallel tempering, on the device
+// ------------------------------------------------------------------------------------------------
+// R = chains x T replicas, global replica g belongs to chain g / T and holds ladder rung rung[g].  One workgroup per
+// chain.  Round `rnd` proposes the disjoint neighbour pairs (k, k+1), k = (rnd & 1), +2, ...: with a, b the replicas
+// holding rungs k and k+1,
+//     arg = (beta_k - beta_{k+1}) (E_a - E_b)                       (fp64)
+//     exchange iff  arg >= 0  or  -arg < neglog_u(word(i = chain T + k, s = rnd, g = 0xffffffff, tag 3))
+// -- Metropolis, min(1, e^arg), with the chain's own bit-reproducible logarithm and Philox stream, so every GPU
+// (and the oracle, oracle/pt_oracle.py) takes the same decisions from the same energies.  Temperatures move, states
+// never do: the kernel swaps the two rung indices and rewrites temps[] of the replicas this GPU owns.
+__global__ void __launch_bounds__(256) k_pt_exchange(const double *__restrict__ energy, int *__restrict__ rung,
+                                                     const double *__restrict__ betas,
+                                                     const float *__restrict__ ladder_temps,
+                                                     float *__restrict__ temps_local, int T, int lo, int hi,
+                                                     uint32_t rnd, uint32_t seed_lo, uint32_t seed_hi,
+                                                     unsigned long long *__restrict__ stats)
+{
+    extern __shared__ int holder[];                          // holder[k] = replica of this chain on rung k
+    const int c = blockIdx.x;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) holder[rung[c * T + t]] = c * T + t;
+    __syncthreads();
+    unsigned int proposed = 0, accepted = 0;
+    for (int k = (int)(rnd & 1u) + 2 * (int)threadIdx.x; k + 1 < T; k += 2 * (int)blockDim.x) {
+        const int a = holder[k], b = holder[k + 1];
+        const double arg = (betas[k] - betas[k + 1]) * (energy[a] - energy[b]);
+        ++proposed;
+        const bool acc = arg >= 0.0 ||
+                         -arg < (double)neglog_u(chain_word_dev((uint32_t)(c * T + k), rnd, 0xffffffffu, 3u, seed_lo, seed_hi));
+        if (acc) {
+            rung[a] = k + 1;
+            rung[b] = k;
+            ++accepted;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const int g = c * T + t;
+        if (g >= lo && g < hi) temps_local[g - lo] = ladder_temps[rung[g]];
+    }
+    if (proposed) { atomicAdd(&stats[0], (unsigned long long)proposed); atomicAdd(&stats[1], (unsigned long long)accepted); }
+}
+
 }  // namespace mi_sa_impl
 using namespace mi_sa_impl;
 
@@ -165,6 +209,12 @@ struct mi_sa_problem {
     int last_launches = 1;                   // kernel launches that served the last anneal
     std::string last_kernel;                 // ... and the kernel(s) they ran
     size_t state_elem = 1;
+    // parallel tempering (mi_sa_tempering_*): ladder, rung of every replica of the run, exchange statistics
+    int pt_T = 0, pt_chains = 0, pt_lo = 0, pt_R_local = 0;
+    int *d_pt_rung = nullptr;
+    double *d_pt_betas = nullptr, *d_pt_energy = nullptr;
+    float *d_pt_ladder = nullptr;
+    unsigned long long *d_pt_stats = nullptr;
 };
 
 namespace {
@@ -292,7 +342,7 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
         // K1x: Q stays in HBM as n padded rows of 2*Qs (zero diagonal), uploaded in blocks of rows
         p->xl_chunks = (n + 4095) / 4096;
         const size_t xstride = (size_t)p->xl_chunks * 4096;
-        rc = [&]() -> int {
+        rc = guarded([&]() -> int {
             HIP_TRY(hipMalloc((void **)&p->d_Q2xl, (size_t)n * xstride * sizeof(float)));
             HIP_TRY(hipMalloc((void **)&p->d_diagxl, xstride * sizeof(float)));
             const int rows_per_block = 256;
@@ -311,28 +361,28 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
             }
             HIP_TRY(hipMemcpy(p->d_diagxl, hd.data(), xstride * sizeof(float), hipMemcpyHostToDevice));
             return MI_OK;
-        }();
+        });
         if (rc) { mi_sa_problem_destroy(p); return rc; }
         *out = p;
         return MI_OK;
     }
-    const int slots = (n + 63) / 64;
-    p->NT = ((slots + 3) / 4) * 4;
-    const size_t stride = (size_t)p->NT * 64;
-    // host-side permute: Qp[i][(g*64+lane)*4+c] = 2*Qs[i][64*(4g+c)+lane] (0 on diagonal / padding)
-    const int diag_row = slots * 64;
-    std::vector<float> hp((size_t)(diag_row + 1) * stride, 0.0f);
-    for (int i = 0; i < n; ++i) {
-        const float *row = Qs + (size_t)i * n;
-        float *dst = hp.data() + (size_t)i * stride;
-        for (int j = 0; j < n; ++j) {
-            if (j == i) continue;
-            const int t = j >> 6, lane = j & 63;
-            dst[((size_t)(t >> 2) * 64 + lane) * 4 + (t & 3)] = row[j] + row[j];
+    rc = guarded([&]() -> int {
+        const int slots = (n + 63) / 64;
+        p->NT = ((slots + 3) / 4) * 4;
+        const size_t stride = (size_t)p->NT * 64;
+        // host-side permute: Qp[i][(g*64+lane)*4+c] = 2*Qs[i][64*(4g+c)+lane] (0 on diagonal / padding)
+        const int diag_row = slots * 64;
+        std::vector<float> hp((size_t)(diag_row + 1) * stride, 0.0f);
+        for (int i = 0; i < n; ++i) {
+            const float *row = Qs + (size_t)i * n;
+            float *dst = hp.data() + (size_t)i * stride;
+            for (int j = 0; j < n; ++j) {
+                if (j == i) continue;
+                const int t = j >> 6, lane = j & 63;
+                dst[((size_t)(t >> 2) * 64 + lane) * 4 + (t & 3)] = row[j] + row[j];
+            }
+            hp[(size_t)diag_row * stride + ((size_t)((i >> 6) >> 2) * 64 + (i & 63)) * 4 + ((i >> 6) & 3)] = row[i];
         }
-        hp[(size_t)diag_row * stride + ((size_t)((i >> 6) >> 2) * 64 + (i & 63)) * 4 + ((i >> 6) & 3)] = row[i];
-    }
-    rc = [&]() -> int {
         HIP_TRY(hipMalloc((void **)&p->d_Qp, hp.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(p->d_Qp, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
         if (p->NT <= kMaxMfmaNT) {
@@ -349,7 +399,7 @@ int mi_sa_problem_create_dense_f32(const float *Qs, int n, double offset, int de
             HIP_TRY(hipMemcpy(p->d_Qm, hm.data(), hm.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         return MI_OK;
-    }();
+    });
     if (rc) { mi_sa_problem_destroy(p); return rc; }
     *out = p;
     return MI_OK;
@@ -465,6 +515,57 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
     return MI_OK;
 }
 
+// Host-only planning step (no device is touched): the slot-independent sweep order of the structured kernels.
+static int plan_slot_order_impl(const int32_t *rowptr, const int32_t *col, int n, int slot, int64_t *perm)
+{
+    const int nslots = (n + slot - 1) / slot;
+    if (nslots <= 1 || n > (1 << 18)) {                      // the greedy pass is O(n * slots): identity beyond 262144
+        for (int i = 0; i < n; ++i) perm[i] = i;
+        return MI_OK;
+    }
+    for (int i = 0; i < n; ++i)
+        if (rowptr[i + 1] < rowptr[i]) return fail(MI_EINVAL, "rowptr is not monotone at %d", i);
+    // variables by descending degree, ties by index (stable counting sort)
+    int maxdeg = 0;
+    for (int i = 0; i < n; ++i) maxdeg = std::max(maxdeg, rowptr[i + 1] - rowptr[i]);
+    std::vector<int> start((size_t)maxdeg + 2, 0), order((size_t)n);
+    for (int i = 0; i < n; ++i) start[(size_t)(maxdeg - (rowptr[i + 1] - rowptr[i])) + 1]++;
+    for (int d = 0; d <= maxdeg; ++d) start[(size_t)d + 1] += start[(size_t)d];
+    for (int i = 0; i < n; ++i) order[(size_t)start[(size_t)(maxdeg - (rowptr[i + 1] - rowptr[i]))]++] = i;
+    std::vector<int> fill((size_t)nslots, 0), cap((size_t)nslots, slot), where((size_t)n, -1), stamp((size_t)nslots, -1);
+    cap[(size_t)nslots - 1] = n - slot * (nslots - 1);
+    for (int v : order) {
+        for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+            if (col[e] < 0 || col[e] >= n) return fail(MI_EINVAL, "bad column %d in row %d", col[e], v);
+            const int w = where[(size_t)col[e]];
+            if (w >= 0) stamp[(size_t)w] = v;                // slot w holds a neighbour of v
+        }
+        // least filled slot that holds no neighbour (ties: lowest index); one that does only as a last resort
+        int best = -1, best_nb = -1;
+        for (int s = 0; s < nslots; ++s) {
+            if (fill[(size_t)s] >= cap[(size_t)s]) continue;
+            if (stamp[(size_t)s] == v) { if (best_nb < 0 || fill[(size_t)s] < fill[(size_t)best_nb]) best_nb = s; }
+            else if (best < 0 || fill[(size_t)s] < fill[(size_t)best]) best = s;
+        }
+        const int s = best >= 0 ? best : best_nb;
+        where[(size_t)v] = s;
+        fill[(size_t)s]++;
+    }
+    // by slot, then by original index
+    std::vector<int> pos((size_t)nslots + 1, 0);
+    for (int i = 0; i < n; ++i) pos[(size_t)where[(size_t)i] + 1]++;
+    for (int s = 0; s < nslots; ++s) pos[(size_t)s + 1] += pos[(size_t)s];
+    for (int i = 0; i < n; ++i) perm[pos[(size_t)where[(size_t)i]]++] = i;
+    return MI_OK;
+}
+
+int mi_sa_plan_slot_order(const int32_t *rowptr, const int32_t *col, int n, int slot, int64_t *out_perm)
+{
+    if (!rowptr || !out_perm || (n > 0 && rowptr[n] > 0 && !col)) return fail(MI_EINVAL, "NULL argument");
+    if (n < 0 || slot < 1) return fail(MI_EINVAL, "n must be >= 0 and slot >= 1");
+    return guarded([&]() -> int { return plan_slot_order_impl(rowptr, col, n, slot, out_perm); });
+}
+
 int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                                        const float *lin, float c_pair, int n, double offset, int device,
                                        mi_sa_problem **out)
@@ -478,15 +579,15 @@ int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col
     if (!p) return fail(MI_ENOMEM, "out of host memory");
     p->kind = MI_KIND_CSR_RANK1; p->n = n; p->K = 2; p->offset = offset; p->state_elem = 1; p->c_pair = c_pair;
     rc = problem_common_init(p, device);
-    if (!rc) rc = upload_slot_ell(p, rowptr, col, val, n);
-    if (!rc) rc = [&]() -> int {
+    if (!rc) rc = guarded([&]() -> int { return upload_slot_ell(p, rowptr, col, val, n); });
+    if (!rc) rc = guarded([&]() -> int {
         // the lanes past n carry lin = +inf: their dE is +inf, never accepted (K2 has no per-lane bound check)
         std::vector<float> hl((size_t)p->slots * 64, INFINITY);
         for (int i = 0; i < n; ++i) hl[i] = lin[i];
         HIP_TRY(hipMalloc((void **)&p->d_lin, hl.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(p->d_lin, hl.data(), hl.size() * sizeof(float), hipMemcpyHostToDevice));
         return MI_OK;
-    }();
+    });
     if (rc) { mi_sa_problem_destroy(p); return rc; }
     *out = p;
     return MI_OK;
@@ -506,13 +607,13 @@ int mi_sa_problem_create_potts_csr_f32(const int32_t *rowptr, const int32_t *col
     if (!p) return fail(MI_ENOMEM, "out of host memory");
     p->kind = MI_KIND_POTTS_CSR; p->n = n; p->K = K; p->offset = lin_offset; p->state_elem = 2; p->c_pair = c_pair;
     rc = problem_common_init(p, device);
-    if (!rc) rc = upload_slot_ell(p, rowptr, col, val, n);
+    if (!rc) rc = guarded([&]() -> int { return upload_slot_ell(p, rowptr, col, val, n); });
     if (rc) { mi_sa_problem_destroy(p); return rc; }
     *out = p;
     return MI_OK;
 }
 
-int mi_sa_problem_set_energy_model_f64(mi_sa_problem *p, const double *val, const double *lin, double c_pair)
+static int set_energy_model_impl(mi_sa_problem *p, const double *val, const double *lin, double c_pair)
 {
     if (!p) return fail(MI_EINVAL, "NULL problem");
     if (p->kind != MI_KIND_CSR_RANK1 && p->kind != MI_KIND_POTTS_CSR)
@@ -536,12 +637,17 @@ int mi_sa_problem_set_energy_model_f64(mi_sa_problem *p, const double *val, cons
     return MI_OK;
 }
 
+int mi_sa_problem_set_energy_model_f64(mi_sa_problem *p, const double *val, const double *lin, double c_pair)
+{
+    return guarded([&]() -> int { return set_energy_model_impl(p, val, lin, c_pair); });
+}
+
 int mi_sa_problem_destroy(mi_sa_problem *p)
 {
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_pt_rung, p->d_pt_betas, p->d_pt_energy, p->d_pt_ladder, p->d_pt_stats, p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -601,35 +707,41 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     return fail(MI_EINVAL, "unknown option '%s'", key);
 }
 
-int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
-                    const double *betas, uint64_t seed, const void *init, int resync_interval,
-                    uint32_t sweep_offset, uint32_t flags)
+static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
+                          const double *betas, uint64_t seed, const void *init, int resync_interval,
+                          uint32_t sweep_offset, uint32_t flags)
 {
-    const bool cont = (flags & MI_F_CONTINUE) != 0, per_replica = (flags & MI_F_BETA_PER_REPLICA) != 0;
+    const bool cont = (flags & MI_F_CONTINUE) != 0, resident = (flags & MI_F_TEMPS_RESIDENT) != 0;
+    const bool per_replica = (flags & MI_F_BETA_PER_REPLICA) != 0 || resident;
     const int num_betas = per_replica ? R : num_sweeps;
-    if (flags & ~(uint32_t)(MI_F_CONTINUE | MI_F_BETA_PER_REPLICA)) return fail(MI_EINVAL, "unknown flags 0x%x", flags);
+    if (flags & ~(uint32_t)(MI_F_CONTINUE | MI_F_BETA_PER_REPLICA | MI_F_TEMPS_RESIDENT)) return fail(MI_EINVAL, "unknown flags 0x%x", flags);
     if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (resident && (p->pt_T == 0 || p->pt_R_local != R))
+        return fail(MI_ESTATE, "MI_F_TEMPS_RESIDENT needs mi_sa_tempering_begin for %d replicas on this problem", R);
     if (R < 1) return fail(MI_EINVAL, "R must be >= 1 (got %d)", R);
     if (num_sweeps < 0) return fail(MI_EINVAL, "num_sweeps must be >= 0");
-    if (num_betas > 0 && num_sweeps > 0 && !betas) return fail(MI_EINVAL, "betas is NULL");
+    if (num_betas > 0 && num_sweeps > 0 && !betas && !resident) return fail(MI_EINVAL, "betas is NULL");
     if (cont && (!p || !p->has_run || p->last_R != R))
         return fail(MI_ESTATE, "MI_F_CONTINUE needs a previous run with the same number of replicas");
     if (cont && init) return fail(MI_EINVAL, "MI_F_CONTINUE and init are mutually exclusive");
     if (resync_interval < 0) return fail(MI_EINVAL, "resync_interval must be >= 0");
-    for (int s = 0; s < (num_sweeps > 0 ? num_betas : 0); ++s)
+    for (int s = 0; s < (num_sweeps > 0 && !resident ? num_betas : 0); ++s)
         if (!(betas[s] > 0.0) || !std::isfinite(betas[s]))
             return fail(MI_EINVAL, "betas[%d] = %g is not a positive finite number", s, betas[s]);
     HIP_TRY(hipSetDevice(p->device));
     int rc = ensure_run_buffers(p, R, num_betas, init != nullptr);
     if (rc) return rc;
-    std::vector<float> temps((size_t)(num_betas > 0 ? num_betas : 1), 1.0f);
-    for (int s = 0; s < (num_sweeps > 0 ? num_betas : 0); ++s) temps[s] = (float)(1.0 / betas[s]);
-    // pageable-host async copies are staged synchronously by the runtime: the vector may go away
-    HIP_TRY(hipMemcpyAsync(p->d_temps, temps.data(), temps.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    if (!resident) {                             // (tempering rounds: the exchange kernel keeps temps[] up to date)
+        std::vector<float> temps((size_t)(num_betas > 0 ? num_betas : 1), 1.0f);
+        for (int s = 0; s < (num_sweeps > 0 ? num_betas : 0); ++s) temps[s] = (float)(1.0 / betas[s]);
+        // pageable-host async copies are staged synchronously by the runtime: the vector may go away
+        HIP_TRY(hipMemcpyAsync(p->d_temps, temps.data(), temps.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    }
     if (init)
         HIP_TRY(hipMemcpyAsync(p->d_init, init, (size_t)R * p->n * p->state_elem, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_stats, 0, 16 * sizeof(unsigned long long), p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));   // inputs resident before the timed region
+    if (!resident || init)
+        HIP_TRY(hipStreamSynchronize(p->stream));   // inputs resident before the timed region
     g_kernel.clear();
 
     if (p->kind == MI_KIND_DENSE && p->xl_chunks > 0) {
@@ -689,6 +801,95 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
     p->last_R = R; p->last_offset = replica_offset; p->has_run = true;
     p->last_kernel = g_kernel;
     return MI_OK;
+}
+
+int mi_sa_tempering_begin(mi_sa_problem *p, const double *ladder_betas, int T, int chains,
+                          uint32_t first_replica, int R_local)
+{
+    if (!p || !ladder_betas) return fail(MI_EINVAL, "NULL argument");
+    if (T < 2 || T > 1024) return fail(MI_EINVAL, "a tempering ladder has 2 .. 1024 temperatures (got %d)", T);
+    if (chains < 1) return fail(MI_EINVAL, "chains must be >= 1");
+    const long long total = (long long)T * chains;
+    if (R_local < 1 || (long long)first_replica + R_local > total)
+        return fail(MI_EINVAL, "local replicas [%u, %u + %d) do not lie inside the %lld replicas of the run", first_replica, first_replica, R_local, total);
+    for (int k = 0; k < T; ++k)
+        if (!(ladder_betas[k] > 0.0) || !std::isfinite(ladder_betas[k]))
+            return fail(MI_EINVAL, "ladder beta %d = %g is not a positive finite number", k, ladder_betas[k]);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc = ensure_run_buffers(p, R_local, R_local, false);
+    if (rc) return rc;
+    for (void *b : {(void *)p->d_pt_rung, (void *)p->d_pt_betas, (void *)p->d_pt_energy, (void *)p->d_pt_ladder, (void *)p->d_pt_stats})
+        if (b) (void)hipFree(b);
+    p->d_pt_rung = nullptr; p->d_pt_betas = nullptr; p->d_pt_energy = nullptr; p->d_pt_ladder = nullptr; p->d_pt_stats = nullptr;
+    p->pt_T = 0;
+    rc = guarded([&]() -> int {
+        std::vector<int> rung((size_t)total);
+        for (long long g = 0; g < total; ++g) rung[(size_t)g] = (int)(g % T);
+        std::vector<float> lt((size_t)T), local((size_t)R_local);
+        for (int k = 0; k < T; ++k) lt[(size_t)k] = (float)(1.0 / ladder_betas[k]);
+        for (int r = 0; r < R_local; ++r) local[(size_t)r] = lt[(size_t)(((long long)first_replica + r) % T)];
+        HIP_TRY(hipMalloc((void **)&p->d_pt_rung, (size_t)total * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&p->d_pt_betas, (size_t)T * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&p->d_pt_energy, (size_t)total * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&p->d_pt_ladder, (size_t)T * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&p->d_pt_stats, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpy(p->d_pt_rung, rung.data(), rung.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_pt_betas, ladder_betas, (size_t)T * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_pt_ladder, lt.data(), lt.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_temps, local.data(), local.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(p->d_pt_stats, 0, 2 * sizeof(unsigned long long)));
+        return MI_OK;
+    });
+    if (rc) return rc;
+    p->pt_T = T; p->pt_chains = chains; p->pt_lo = (int)first_replica; p->pt_R_local = R_local;
+    return MI_OK;
+}
+
+int mi_sa_tempering_exchange(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *all_energies)
+{
+    if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (p->pt_T == 0) return fail(MI_ESTATE, "mi_sa_tempering_begin has not been called on this problem");
+    if (!p->has_run || p->last_R != p->pt_R_local) return fail(MI_ESTATE, "no tempering round has run on this problem");
+    const long long total = (long long)p->pt_T * p->pt_chains;
+    if (!all_energies && p->pt_R_local != total)
+        return fail(MI_EINVAL, "this GPU holds %d of the %lld replicas: the exchange needs all energies", p->pt_R_local, total);
+    HIP_TRY(hipSetDevice(p->device));
+    const double *en = p->d_energy;              // one GPU owns every replica: the energies never leave HBM
+    if (all_energies) {
+        HIP_TRY(hipMemcpyAsync(p->d_pt_energy, all_energies, (size_t)total * sizeof(double), hipMemcpyHostToDevice, p->stream));
+        en = p->d_pt_energy;
+    }
+    hipLaunchKernelGGL(k_pt_exchange, dim3(p->pt_chains), dim3(256), (size_t)p->pt_T * sizeof(int), p->stream, en,
+                       p->d_pt_rung, p->d_pt_betas, p->d_pt_ladder, p->d_temps, p->pt_T, p->pt_lo, p->pt_lo + p->pt_R_local,
+                       round, (uint32_t)seed, (uint32_t)(seed >> 32), p->d_pt_stats);
+    HIP_TRY(hipGetLastError());
+    if (all_energies) HIP_TRY(hipStreamSynchronize(p->stream));      // the caller's buffer may go away
+    return MI_OK;
+}
+
+int mi_sa_tempering_state(mi_sa_problem *p, int32_t *out_rung, uint64_t *out_proposed, uint64_t *out_accepted)
+{
+    if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (p->pt_T == 0) return fail(MI_ESTATE, "mi_sa_tempering_begin has not been called on this problem");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (out_rung)
+        HIP_TRY(hipMemcpy(out_rung, p->d_pt_rung, (size_t)p->pt_T * p->pt_chains * sizeof(int), hipMemcpyDeviceToHost));
+    unsigned long long st[2];
+    HIP_TRY(hipMemcpy(st, p->d_pt_stats, sizeof st, hipMemcpyDeviceToHost));
+    if (out_proposed) *out_proposed = st[0];
+    if (out_accepted) *out_accepted = st[1];
+    return MI_OK;
+}
+
+int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,
+                    const double *betas, uint64_t seed, const void *init, int resync_interval,
+                    uint32_t sweep_offset, uint32_t flags)
+{
+    return guarded([&]() -> int {
+        return anneal_ex_impl(p, R, replica_offset, num_sweeps, betas, seed, init, resync_interval, sweep_offset, flags);
+    });
 }
 
 int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweeps,

@@ -5,6 +5,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <exception>
+#include <new>
 #include <type_traits>
 
 #include "../../include/mi_sa.h"
@@ -13,6 +15,22 @@ namespace mi_sa_impl {
 
 int fail(int code, const char *fmt, ...);
 void note_kernel(const char *fmt, ...);      // the launchers record which kernel serves the running anneal (mi_sa_last_kernel_name)
+
+// No C++ exception may cross the C ABI: every extern "C" entry that allocates host memory runs its body through
+// guarded(), which turns std::bad_alloc (and anything else) into an MI_E* code + mi_last_error() text.
+template <typename F>
+int guarded(F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(MI_ENOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MI_EINVAL, "unexpected C++ exception: %s", e.what());
+    } catch (...) {
+        return fail(MI_EINVAL, "unexpected C++ exception");
+    }
+}
 
 #define HIP_TRY(expr)                                                                            \
     do {                                                                                         \

@@ -573,9 +573,13 @@ int mi_snn_fetch(mi_snn_graph *g, int32_t *nn, int64_t *rowptr, int32_t *col, in
     HIP_TRY(hipSetDevice(g->device));
     if (nn) HIP_TRY(hipMemcpy(nn, g->d_nn, (size_t)g->n * g->k * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (rowptr) {
-        std::vector<int> tmp((size_t)g->n + 1);
-        HIP_TRY(hipMemcpy(tmp.data(), g->d_ptr, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < tmp.size(); ++i) rowptr[i] = tmp[i];
+        const int rc = guarded([&]() -> int {
+            std::vector<int> tmp((size_t)g->n + 1);
+            HIP_TRY(hipMemcpy(tmp.data(), g->d_ptr, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < tmp.size(); ++i) rowptr[i] = tmp[i];
+            return MI_OK;
+        });
+        if (rc) return rc;
     }
     if (col && g->nnz) HIP_TRY(hipMemcpy(col, g->d_col, (size_t)g->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (shared && g->nnz) HIP_TRY(hipMemcpy(shared, g->d_shared, (size_t)g->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -161,13 +161,18 @@ class Problem:
                initial_states: Optional[np.ndarray] = None, resync_interval: int = 0,
                sweep_offset: int = 0, continue_run: bool = False, num_sweeps: Optional[int] = None):
         """``betas``: one per sweep (default), or -- when ``num_sweeps`` is given -- one per REPLICA, held
-        constant for ``num_sweeps`` sweeps (a tempering rung).  ``continue_run`` starts from the states the
-        previous call left on the device; ``sweep_offset`` continues its random stream."""
-        betas = np.ascontiguousarray(betas, dtype=np.float64)
+        constant for ``num_sweeps`` sweeps (a tempering rung); ``betas=None`` with ``num_sweeps``: every replica
+        at the temperature the device-side tempering state holds for it (``tempering_begin`` / ``_exchange``).
+        ``continue_run`` starts from the states the previous call left on the device; ``sweep_offset`` continues
+        its random stream."""
+        resident = betas is None
+        if resident and num_sweeps is None:
+            raise ValueError("betas=None (temperatures resident on the device) needs num_sweeps")
+        betas = None if resident else np.ascontiguousarray(betas, dtype=np.float64)
         per_replica = num_sweeps is not None
-        if per_replica and len(betas) != num_reads:
+        if per_replica and not resident and len(betas) != num_reads:
             raise ValueError("per-replica betas need one entry per replica")
-        flags = (1 if continue_run else 0) | (2 if per_replica else 0)
+        flags = (1 if continue_run else 0) | (2 if per_replica else 0) | (4 if resident else 0)
         sweeps = int(num_sweeps) if per_replica else len(betas)
         init = None
         if initial_states is not None:
@@ -183,6 +188,30 @@ class Problem:
             init.ctypes.data_as(C.c_void_p) if init is not None else None, int(resync_interval),
             C.c_uint32(int(sweep_offset) & 0xFFFFFFFF), C.c_uint32(flags)))
         self._last = (int(num_reads), sweeps)
+
+    # -- parallel tempering: exchange step on the device (K6) ----------------------------------------
+    def tempering_begin(self, ladder_betas, chains: int, first_replica: int, num_local: int):
+        lad = np.ascontiguousarray(ladder_betas, dtype=np.float64)
+        self._pt_total = len(lad) * int(chains)
+        _lib.check(_lib.load().mi_sa_tempering_begin(self._h, _ptr(lad, C.c_double), len(lad), int(chains),
+                                                     C.c_uint32(int(first_replica)), int(num_local)))
+
+    def tempering_exchange(self, rnd: int, seed: int, all_energies: Optional[np.ndarray] = None):
+        """Neighbouring rungs of every chain exchange (Metropolis on a counter-based stream of (seed, round)).
+        ``all_energies`` = None when this GPU owns every replica (nothing leaves HBM), else the all-gathered
+        energies of the run in global replica order."""
+        en = None if all_energies is None else np.ascontiguousarray(all_energies, dtype=np.float64)
+        if en is not None and len(en) != self._pt_total:
+            raise ValueError("all_energies must hold the %d energies of the run" % self._pt_total)
+        _lib.check(_lib.load().mi_sa_tempering_exchange(self._h, C.c_uint32(int(rnd) & 0xFFFFFFFF),
+                                                        C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _ptr(en, C.c_double)))
+
+    def tempering_state(self):
+        """``(rung of every replica of the run, exchanges proposed, exchanges accepted)``."""
+        rung = np.empty(self._pt_total, dtype=np.int32)
+        prop, acc = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(_lib.load().mi_sa_tempering_state(self._h, _ptr(rung, C.c_int32), C.byref(prop), C.byref(acc)))
+        return rung.astype(np.int64), int(prop.value), int(acc.value)
 
     def sync(self):
         _lib.check(_lib.load().mi_sa_sync(self._h))

@@ -1,17 +1,20 @@
 """Parallel tempering (replica exchange) on top of the anneal kernels -- BASELINE config 5.
 
 R = T x C replicas: C independent chains of T temperature rungs.  A round is ``sweeps_per_round`` sweeps
-with every replica at the constant beta of the rung it currently holds (``MI_F_BETA_PER_REPLICA``),
-continuing from the states left in HBM (``MI_F_CONTINUE``) with the random stream advanced by
-``sweep_offset``; then neighbouring rungs of each chain propose to exchange with the Metropolis rule
-``min(1, exp((beta_k - beta_{k+1}) (E_k - E_{k+1})))``, even pairs on even rounds, odd pairs on odd rounds.
+with every replica at the constant beta of the rung it currently holds, continuing from the states left in HBM
+(``MI_F_CONTINUE``) with the random stream advanced by ``sweep_offset``; then neighbouring rungs of each chain
+propose to exchange with the Metropolis rule ``min(1, exp((beta_k - beta_{k+1}) (E_k - E_{k+1})))``, even pairs
+on even rounds, odd pairs on odd rounds.
 
-**Temperatures move, states do not**: an accepted exchange swaps the two replicas' rung indices only.
-Across GPUs the per-round exchange is ONE all-gather of the R energies (``distributed.gather_energies``,
-RCCL on GPUs / gloo in the CPU tests); every rank then derives the identical exchange decisions from a
-shared counter-based stream (seed, round), so no state ever crosses xGMI.
+**Temperatures move, states do not**: an accepted exchange swaps the two replicas' rung indices only.  The
+exchange is kernel K6 (`csrc/mi_sa.hip:k_pt_exchange`, C ABI ``mi_sa_tempering_*``): on one GPU the energies,
+the rungs and the per-replica temperatures the next round anneals at never leave HBM -- a round is two kernel
+launches and no copy.  Across GPUs the per-round exchange is ONE all-gather of the R energies
+(``distributed.gather_energies``, RCCL on GPUs / gloo in the CPU tests); every rank then runs the same exchange
+kernel on the same energies with the same counter-based stream (seed, round), so no state ever crosses xGMI.
 
-The exchange itself is O(R) host arithmetic on 8 bytes per replica; the sweeps are the kernels.
+The driver below only sequences rounds; an *engine* supplies ``begin / round / exchange / energies / states /
+rungs`` (``ProblemEngine`` = the GPU; the tests have one backed by the CPU oracle).
 """
 from __future__ import annotations
 
@@ -29,17 +32,24 @@ def geometric_ladder(beta_hot: float, beta_cold: float, num_temps: int) -> np.nd
 
 
 class ProblemEngine:
-    """Adapter: ``engine.Problem`` -> the three calls the tempering driver needs."""
+    """``engine.Problem`` behind the tempering driver: rounds and exchanges are kernels on the problem's stream."""
 
     def __init__(self, problem, seed: int, resync_interval: int = 0):
         self.problem = problem
         self.seed = int(seed)
         self.resync = int(resync_interval)
 
-    def round(self, betas_local, num_sweeps, sweep_offset, replica_offset, first, initial_states=None):
-        self.problem.anneal(len(betas_local), betas_local, self.seed, replica_offset=replica_offset,
+    def begin(self, ladder, chains, lo, hi):
+        self.problem.tempering_begin(ladder, chains, lo, hi - lo)
+        self._n_local, self._lo = hi - lo, lo
+
+    def round(self, num_sweeps, sweep_offset, first, initial_states=None):
+        self.problem.anneal(self._n_local, None, self.seed, replica_offset=self._lo,
                             initial_states=initial_states if first else None, resync_interval=self.resync,
                             sweep_offset=sweep_offset, continue_run=not first, num_sweeps=num_sweeps)
+
+    def exchange(self, rnd, seed, all_energies=None):
+        self.problem.tempering_exchange(rnd, seed, all_energies)
 
     def energies(self) -> np.ndarray:
         return self.problem.fetch(states=False)[1]
@@ -47,58 +57,44 @@ class ProblemEngine:
     def states(self) -> np.ndarray:
         return self.problem.fetch(energies=False)[0]
 
-
-def exchange_step(energies: np.ndarray, rung: np.ndarray, ladder: np.ndarray, num_temps: int, rnd: int,
-                  seed: int):
-    """One exchange phase over ALL replicas (identical on every rank).  ``rung[g]`` = ladder index held by
-    global replica g; chain of g = g // num_temps.  Returns (new rung array, proposed, accepted)."""
-    R = len(energies)
-    chains = R // num_temps
-    rung = rung.copy()
-    energies = np.asarray(energies, dtype=np.float64)
-    holder = np.empty((chains, num_temps), dtype=np.int64)          # holder[c, k] = replica holding rung k
-    g = np.arange(R)
-    holder[g // num_temps, rung] = g
-    rs = np.random.RandomState([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF, rnd & 0x7FFFFFFF, 0x5157])
-    u = rs.random_sample((chains, num_temps))
-    ks = np.arange(rnd & 1, num_temps - 1, 2)                       # disjoint pairs (k, k+1): all at once
-    a, b = holder[:, ks], holder[:, ks + 1]
-    arg = (ladder[ks] - ladder[ks + 1])[None, :] * (energies[a] - energies[b])
-    acc = (arg >= 0.0) | (u[:, ks] < np.exp(np.minimum(arg, 0.0)))
-    up = np.broadcast_to(ks[None, :], acc.shape)
-    rung[a[acc]] = up[acc] + 1
-    rung[b[acc]] = up[acc]
-    proposed, accepted = int(acc.size), int(np.count_nonzero(acc))
-    return rung, proposed, accepted
+    def rungs(self):
+        return self.problem.tempering_state()
 
 
 def parallel_tempering(engine, ladder, chains: int, rounds: int, sweeps_per_round: int, seed: int,
-                       rank: int = 0, world: int = 1, group=None, initial_states: Optional[np.ndarray] = None):
+                       rank: int = 0, world: int = 1, group=None, initial_states: Optional[np.ndarray] = None,
+                       history: bool = True):
     """Run PT on this rank's shard of the R = len(ladder) * chains replicas.
 
     Returns a dict: ``energies`` (all R, global order), ``rung`` (final rung of every replica),
     ``local_states`` (this rank's final states), ``best_energy`` / ``best_replica`` (global),
-    ``swap_rate``, ``history`` (best energy after every round)."""
+    ``swap_rate``, ``history`` (best energy after every round; ``history=False`` skips the per-round read of the
+    energies -- on one GPU a round then involves no host copy at all)."""
     ladder = np.ascontiguousarray(ladder, dtype=np.float64)
     T = len(ladder)
     R = T * int(chains)
     lo, hi = D.shard_range(R, rank, world)
-    rung = np.arange(R, dtype=np.int64) % T
-    proposed = accepted = 0
-    history = []
-    energies = None
+    engine.begin(ladder, int(chains), lo, hi)
+    hist = []
     for rnd in range(int(rounds)):
-        engine.round(ladder[rung[lo:hi]], int(sweeps_per_round), rnd * int(sweeps_per_round), lo, rnd == 0,
-                     initial_states)
-        energies = D.gather_energies(engine.energies(), group=group)          # (C3) R doubles
-        history.append(float(energies.min()))
-        if rnd + 1 < rounds:
-            rung, p, a = exchange_step(energies, rung, ladder, T, rnd, seed)
-            proposed += p
-            accepted += a
+        engine.round(int(sweeps_per_round), rnd * int(sweeps_per_round), rnd == 0, initial_states)
+        last = rnd + 1 == rounds
+        if world > 1:
+            energies = D.gather_energies(engine.energies(), group=group)      # (C3) R doubles
+            if history:
+                hist.append(float(energies.min()))
+            if not last:
+                engine.exchange(rnd, seed, energies)
+        else:
+            if history:
+                hist.append(float(engine.energies().min()))
+            if not last:
+                engine.exchange(rnd, seed, None)
+    energies = D.gather_energies(engine.energies(), group=group)
+    rung, proposed, accepted = engine.rungs()
     best = int(np.argmin(energies))
     return {
         "energies": energies, "rung": rung, "local_range": (lo, hi), "local_states": engine.states(),
         "best_energy": float(energies[best]), "best_replica": best,
-        "swap_rate": (accepted / proposed) if proposed else 0.0, "history": history,
+        "swap_rate": (accepted / proposed) if proposed else 0.0, "history": hist,
     }

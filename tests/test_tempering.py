@@ -1,35 +1,53 @@
-"""Parallel tempering: exchange rule (CPU), 2-rank gloo equivalence with the oracle as the engine (CPU),
-and -- on the GPU -- continuation / per-replica-beta parity of the kernels plus an end-to-end PT run."""
+"""Parallel tempering: exchange rule (CPU restatement), 2-rank gloo equivalence with the oracle as the engine
+(CPU), and -- on the GPU -- continuation / per-replica-beta parity of the kernels, the exchange kernel K6 against
+its restatement, and an end-to-end PT run."""
 import os
 
 import numpy as np
 import pytest
 
 from conftest import load_fixture
+from oracle import pt_oracle
 from oracle import sa_oracle as so
 from scrna_seq_qannealing_clustering_amd import distributed as D
 from scrna_seq_qannealing_clustering_amd import models, tempering
 
 
 class OracleEngine:
-    """The CPU oracle behind the tempering driver's engine interface (tests only)."""
+    """The CPU oracle behind the tempering driver's engine interface (tests only): the anneal chains of
+    oracle/sa_oracle.c and the exchange rule of oracle/pt_oracle.py."""
 
     def __init__(self, kind, args, seed, **kw):
         self.kind, self.args, self.seed, self.kw = kind, args, seed, kw
         self.st = self.en = None
 
-    def round(self, betas_local, num_sweeps, sweep_offset, replica_offset, first, initial_states=None):
+    def begin(self, ladder, chains, lo, hi):
+        self.ladder, self.T, self.lo, self.hi = np.asarray(ladder, dtype=np.float64), len(ladder), lo, hi
+        self.rung = np.arange(len(ladder) * chains, dtype=np.int64) % len(ladder)
+        self.proposed = self.accepted = 0
+
+    def round(self, num_sweeps, sweep_offset, first, initial_states=None):
         init = initial_states if first else self.st
+        betas_local = self.ladder[self.rung[self.lo:self.hi]]
         fn = {"dense": so.sa_dense_philox, "csr": so.sa_csr_rank1_philox, "potts": so.potts_csr_philox}[self.kind]
         self.st, self.en, _ = fn(*self.args, len(betas_local), betas_local, self.seed,
-                                 replica_offset=replica_offset, init=init, sweep_offset=sweep_offset,
+                                 replica_offset=self.lo, init=init, sweep_offset=sweep_offset,
                                  num_sweeps=num_sweeps, **self.kw)
+
+    def exchange(self, rnd, seed, all_energies=None):
+        en = self.en if all_energies is None else all_energies
+        self.rung, p, a = pt_oracle.exchange_step(en, self.rung, self.ladder, self.T, rnd, seed)
+        self.proposed += p
+        self.accepted += a
 
     def energies(self):
         return self.en
 
     def states(self):
         return self.st
+
+    def rungs(self):
+        return self.rung, self.proposed, self.accepted
 
 
 def potts_case(name="blobs", K=3, gamma=0.05):
@@ -45,17 +63,29 @@ def test_exchange_rule_is_metropolis_and_moves_rungs_only():
     en = np.array([5.0, 1.0, 2.0, 3.0, 0.0, 0.0, 0.0, 0.0])
     # pair (0,1) of chain 0: hotter replica has HIGHER energy -> arg = (b0-b1)(E0-E1) < 0 -> random;
     # with energies reversed the swap is certain
-    new, p, a = tempering.exchange_step(np.array([1.0, 5.0, 2.0, 3.0, 0, 0, 0, 0]), rung, ladder, 4, 0, 7)
+    new, p, a = pt_oracle.exchange_step(np.array([1.0, 5.0, 2.0, 3.0, 0, 0, 0, 0]), rung, ladder, 4, 0, 7)
     assert p == 4 and new[0] == 1 and new[1] == 0                    # certain swap: colder rung gets lower E
     assert sorted(new[:4].tolist()) == [0, 1, 2, 3] and sorted(new[4:].tolist()) == [0, 1, 2, 3]
-    n2, _, _ = tempering.exchange_step(en, rung, ladder, 4, 1, 7)   # odd round: pairs (1,2) only
+    n2, _, _ = pt_oracle.exchange_step(en, rung, ladder, 4, 1, 7)   # odd round: pairs (1,2) only
     assert n2[0] == 0 and n2[3] == 3
     # deterministic in (seed, round)
-    x1 = tempering.exchange_step(en, rung, ladder, 4, 0, 99)[0]
-    x2 = tempering.exchange_step(en, rung, ladder, 4, 0, 99)[0]
+    x1 = pt_oracle.exchange_step(en, rung, ladder, 4, 0, 99)[0]
+    x2 = pt_oracle.exchange_step(en, rung, ladder, 4, 0, 99)[0]
     assert np.array_equal(x1, x2)
     with pytest.raises(ValueError):
         tempering.geometric_ladder(1, 2, 1)
+
+
+def test_exchange_acceptance_rate_is_metropolis():
+    """Over many independent pairs with a fixed arg < 0 the accepted share is exp(arg) (the log form
+    -arg < -ln u of the rule, with the chain's own logarithm and random words)."""
+    chains, T = 4000, 2
+    ladder = np.array([1.0, 2.0])
+    for gap, rnd in ((0.25, 0), (1.5, 2)):
+        en = np.tile(np.array([gap, 0.0]), chains)            # arg = (1 - 2) * (gap - 0) = -gap
+        _, p, a = pt_oracle.exchange_step(en, np.arange(2 * chains) % 2, ladder, T, rnd, 1234)
+        assert p == chains
+        assert abs(a / p - np.exp(-gap)) < 4.0 * np.sqrt(np.exp(-gap) * (1 - np.exp(-gap)) / chains)
 
 
 def test_oracle_continuation_equals_one_long_run():
@@ -165,31 +195,41 @@ def test_gpu_parallel_tempering_matches_oracle_engine_and_improves_on_sa():
     assert out["best_energy"] <= e_comp * (1 - 1e-6)          # device energies use the fp32-stored coefficients
 
 
-def test_exchange_step_equals_the_pairwise_loop():
-    """The vectorised exchange phase against the plain loop over chains and neighbouring rungs."""
-    from scrna_seq_qannealing_clustering_amd.tempering import exchange_step
+@pytest.mark.gpu
+def test_gpu_exchange_kernel_equals_the_restatement():
+    """K6 (mi_sa_tempering_exchange) against oracle/pt_oracle.py on arbitrary energies: same rungs, same counts,
+    even and odd rounds, ladders of 2 .. 300 temperatures, several rounds chained (rungs no longer in order), and
+    the temperatures the next round anneals at follow the rungs."""
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    fx, pm, args = potts_case("blobs", 3, 0.05)
     rs = np.random.RandomState(5)
-    for T, chains, rnd in ((2, 1, 0), (5, 7, 0), (5, 7, 1), (8, 16, 3), (3, 4, 2)):
-        R = T * chains
-        ladder = np.geomspace(0.3, 9.0, T)
-        energies = rs.normal(scale=3.0, size=R)
-        rung = np.concatenate([rs.permutation(T) for _ in range(chains)]).astype(np.int64)
-        seed = 77
-        got, gp, ga = exchange_step(energies, rung, ladder, T, rnd, seed)
-        want = rung.copy()
-        holder = np.empty((chains, T), dtype=np.int64)
-        for g in range(R):
-            holder[g // T, rung[g]] = g
-        u = np.random.RandomState([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF, rnd & 0x7FFFFFFF, 0x5157]
-                                  ).random_sample((chains, T))
-        p = acc = 0
-        for c in range(chains):
-            for k in range(rnd & 1, T - 1, 2):
-                a, b = holder[c, k], holder[c, k + 1]
-                arg = (ladder[k] - ladder[k + 1]) * (energies[a] - energies[b])
-                p += 1
-                if arg >= 0.0 or u[c, k] < np.exp(arg):
-                    want[a], want[b] = k + 1, k
-                    acc += 1
-        assert np.array_equal(got, want) and (gp, ga) == (p, acc)
-        assert np.array_equal(np.sort(got.reshape(chains, T), axis=1), np.tile(np.arange(T), (chains, 1)))
+    with Problem.potts_csr(*args, lin_offset=pm.lin_offset) as p:
+        for T, chains in ((2, 1), (5, 7), (8, 16), (3, 4), (300, 2)):
+            R = T * chains
+            ladder = np.geomspace(0.3, 9.0, T)
+            p.tempering_begin(ladder, chains, 0, R)
+            p.anneal(R, None, 3, num_sweeps=1)                              # a run must exist before an exchange
+            rung = np.arange(R, dtype=np.int64) % T
+            tot_p = tot_a = 0
+            for rnd in range(5):
+                energies = rs.normal(scale=3.0, size=R)
+                p.tempering_exchange(rnd, 77, energies)
+                rung, pp, aa = pt_oracle.exchange_step(energies, rung, ladder, T, rnd, 77)
+                tot_p, tot_a = tot_p + pp, tot_a + aa
+                got, gp, ga = p.tempering_state()
+                assert np.array_equal(got, rung) and (gp, ga) == (tot_p, tot_a)
+                assert np.array_equal(np.sort(got.reshape(chains, T), axis=1), np.tile(np.arange(T), (chains, 1)))
+            assert 0 < tot_a < tot_p or T == 2
+            # the next round runs every replica at its rung's temperature: equal to per-replica betas given by hand
+            p.anneal(R, None, 3, num_sweeps=4, sweep_offset=50, continue_run=True)
+            lab, en, _ = p.fetch()
+            p.anneal(R, None, 3, num_sweeps=1)
+            p.anneal(R, ladder[rung], 3, num_sweeps=4, sweep_offset=50, continue_run=True)
+            lab2, en2, _ = p.fetch()
+            assert np.array_equal(lab, lab2) and np.array_equal(en, en2)
+        with pytest.raises(_lib_error()):
+            p.tempering_exchange(0, 1, np.zeros(3))
+
+
+def _lib_error():
+    return (ValueError, __import__("scrna_seq_qannealing_clustering_amd")._lib.MiSaError)
