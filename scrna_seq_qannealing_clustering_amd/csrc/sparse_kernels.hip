@@ -566,7 +566,56 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             };
             // the two wave-uniform switches select one of four straight-line copies of the loop (inside it they
             // would be a ladder of taken branches on the serial path)
-            if (!use_min && onehot && has_in == 0ull) {
+            if (has_in == 0ull && K <= 16) {
+                // ---- no variable of this slot has a neighbour inside it (every slot under the slot-independent
+                // order): a lane's decision depends on the movers below it only through the sizes of ITS two clusters.
+                // As in K2, the accept mask of the sequential sweep is the one fixed point of "evaluate every lane
+                // under a guessed mask, rebuild the mask" -- reached in 2-3 rounds instead of one trip through a
+                // dependent vector -> scalar -> vector chain per mover.  The sizes the movers below lane i leave
+                // behind come from ONE wave-wide prefix sum: lane j contributes a byte per cluster, 1 + [j moves into
+                // it] - [j moves out of it] (0, 1 or 2: never a borrow between bytes, sums <= 128), so after the scan
+                // byte q of lane i holds i + (net change of cluster q by the movers below i), and the index cancels in
+                // the difference of the lane's two clusters.  K <= 8 clusters fill one 64-bit value, K <= 16 two.
+                const bool two = K > 8;                           // wave-uniform
+                auto unit = [&](int q) -> unsigned long long { return 1ull << ((q & 7) * 8); };
+                const unsigned long long ones = 0x0101010101010101ull;
+                // this lane's contribution when it moves (la -> lb), per 64-bit half
+                unsigned long long mv0 = ones, mv1 = ones;
+                if (lb < 8) mv0 += unit(lb); else mv1 += unit(lb);
+                if (la < 8) mv0 -= unit(la); else mv1 -= unit(la);
+                const int sh_a = (la & 7) * 8, sh_b = (lb & 7) * 8;
+                const float hd = hb - ha;
+                const int d0 = ib - ia;                           // (cnt_b) - (cnt_a - 1) before any move of this slot
+                auto scan32 = [&](uint32_t v) -> uint32_t {       // inclusive prefix sum over the 64 lanes (DPP)
+                    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+                    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+                    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+                    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+                    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+                    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+                    return v;
+                };
+                auto scan64 = [&](unsigned long long v) -> unsigned long long {
+                    return ((unsigned long long)scan32((uint32_t)(v >> 32)) << 32) | scan32((uint32_t)v);
+                };
+                bool mine = fmaf(a.c_pair, (float)d0, hd) < thr && (!use_min || ia >= a.min_size);
+                uint64_t A = __ballot(mine);
+                if (A != 0ull) {                                  // wave-uniform
+                    for (int round = 0; round < 66; ++round) {
+                        // exclusive prefix: the inclusive scan minus the lane's own contribution
+                        const unsigned long long c0 = mine ? mv0 : ones, c1 = mine ? mv1 : ones;
+                        const unsigned long long s0 = scan64(c0) - c0;
+                        const unsigned long long s1 = two ? scan64(c1) - c1 : 0ull;
+                        const int na = (int)(((la < 8 ? s0 : s1) >> sh_a) & 0xffull);   // lane index + net change of cluster a
+                        const int nb = (int)(((lb < 8 ? s0 : s1) >> sh_b) & 0xffull);
+                        mine = fmaf(a.c_pair, (float)(d0 + nb - na), hd) < thr && (!use_min || ia + (na - lane) >= a.min_size);
+                        const uint64_t A2 = __ballot(mine);
+                        if (A2 == A) break;
+                        A = A2;
+                    }
+                }
+                flipped = A;
+            } else if (!use_min && onehot && has_in == 0ull) {
                 // The common case -- no size constraint, K <= 32, no variable of this slot with a neighbour inside
                 // it (every slot under the slot-independent order) -- hand-scheduled like K2's loop: the lanes
                 // above the last mover are selected by EXEC and each lane carries only the DIFFERENCE of its two

@@ -223,7 +223,7 @@ def test_gpu_exchange_kernel_equals_the_restatement():
             # the next round runs every replica at its rung's temperature: equal to per-replica betas given by hand
             p.anneal(R, None, 3, num_sweeps=4, sweep_offset=50, continue_run=True)
             lab, en, _ = p.fetch()
-            p.anneal(R, None, 3, num_sweeps=1)
+            p.anneal(R, ladder[np.arange(R) % T], 3, num_sweeps=1)          # the state the exchanges started from
             p.anneal(R, ladder[rung], 3, num_sweeps=4, sweep_offset=50, continue_run=True)
             lab2, en2, _ = p.fetch()
             assert np.array_equal(lab, lab2) and np.array_equal(en, en2)
