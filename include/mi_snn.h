@@ -37,7 +37,27 @@ typedef struct mi_snn_graph mi_snn_graph;
 int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int ord, int device,
                      mi_snn_graph **out);
 
-/* nnz = stored (directed) entries of the final graph = 2 x edges; max_degree over its rows. */
+/* The optional variants of the notebooks' graph preparation (all `eval=FALSE` chunks the user runs by hand):
+ *   MI_SNN_TRIM_UNSYMMETRIC  first trim: every COLUMN keeps its `ord` heaviest entries, rows are not touched
+ *                            (Pbmc3k_general_data_preparation.Rmd:77-83, Kidney_data.Rmd:235-242): the matrix
+ *                            becomes asymmetric;
+ *   MI_SNN_ENHANCE_MUTUAL    "Enhance shared edges", Method 2 (Rmd :85-101, Kidney :252-266): entries present in
+ *                            both directions get `bonus` added (2 in the PBMC notebook, 1 in the kidney one);
+ *   MI_SNN_ENHANCE_SUM       A + t(A) (Rmd :103-113, Kidney :246-250, "Method 1");
+ *   ord2 > 0                 "limitation of nodes degrees #2" (Rmd :116-123): the sequential symmetric trim again,
+ *                            on the ENHANCED weights (ranked in fp64 as R ranks them).  Built for symmetric
+ *                            matrices: after a symmetric first trim, or after A + t(A).
+ * The stored rows are the COLUMNS of the result: entry e of row i with col[e] = r is A[r, i] (for a symmetric
+ * result the distinction vanishes).  mi_snn_fetch_codes: per stored entry 0 = w, 1 = w + bonus, 2 = w + w with
+ * w = shared / (2k - shared); the caller evaluates the weights in fp64 exactly as R does. */
+#define MI_SNN_TRIM_UNSYMMETRIC 1u
+#define MI_SNN_ENHANCE_MUTUAL   2u
+#define MI_SNN_ENHANCE_SUM       4u
+int mi_snn_build_ex_f32(const float *X, int n, int dim, int k, double prune, int ord, uint32_t flags, double bonus,
+                        int ord2, int device, mi_snn_graph **out);
+int mi_snn_fetch_codes(mi_snn_graph *g, uint8_t *code);
+
+/* nnz = stored (directed) entries of the final graph (= 2 x edges when it is symmetric); max_degree over its rows. */
 int mi_snn_info(const mi_snn_graph *g, int *n, int *k, int64_t *nnz, int *max_degree);
 
 /* Copy to host (each pointer nullable): nn  n x k neighbour indices (column 0 = the point itself, then

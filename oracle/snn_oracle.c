@@ -159,3 +159,51 @@ int orc_snn_trim(int n, const int64_t *rowptr, const int32_t *col, const int32_t
     free(ent);
     return 0;
 }
+
+/* ---- the optional variants of the notebooks (Pbmc3k_general_data_preparation.Rmd:77-123, Kidney_data.Rmd:235-266) ----
+ * The stored rows double as the COLUMNS of the symmetric SNN matrix: entry e of row i with col[e] = r is A[r, i]. */
+
+/* :77-83 "UNSYMMETRIC": for (i) { to_delete <- order(snn[,i], decreasing=TRUE)[(ord+1):n]; snn[,i][to_delete] <- 0 }
+ * -- only column i is written, so the columns are independent.  key = what the column is ranked by. */
+int orc_snn_trim_cols(int n, const int64_t *rowptr, const int32_t *key, int ord, uint8_t *alive)
+{
+    if (ord <= 0) return 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t b = rowptr[i], e1 = rowptr[i + 1];
+        if (e1 - b <= ord) continue;
+        for (int64_t e = b; e < e1; ++e) {
+            int rank = 0;
+            for (int64_t f = b; f < e1; ++f)                      /* stable order(): heavier first, ties by row index */
+                rank += (key[f] > key[e] || (key[f] == key[e] && f < e)) ? 1 : 0;
+            if (rank >= ord) alive[e] = 0;
+        }
+    }
+    return 0;
+}
+
+static int64_t mirror_of(const int64_t *rowptr, const int32_t *col, int r, int i)
+{
+    int64_t lo = rowptr[r], hi = rowptr[r + 1] - 1;
+    while (lo <= hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (col[mid] == i) return mid;
+        if (col[mid] < i) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+/* mode 1 (:85-101): mutual[i,] <- snn[i,] & snn[,i]; snn[i,] <- old[i,] + bonus * mutual[i,]  -> code 1 on entries present
+ * in both directions, support unchanged.  mode 2 (:103-113): snn[i,] <- old[i,] + old[,i]  -> support = union, code 2 where
+ * both were present (the weight doubles). */
+int orc_snn_enhance(int n, int mode, const int64_t *rowptr, const int32_t *col, const uint8_t *alive_in,
+                    uint8_t *alive_out, uint8_t *code)
+{
+    for (int i = 0; i < n; ++i)
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const int64_t m = mirror_of(rowptr, col, col[e], i);
+            const int here = alive_in[e] != 0, there = m >= 0 && alive_in[m] != 0;
+            if (mode == 1) { alive_out[e] = (uint8_t)here; code[e] = (uint8_t)(here && there ? 1 : 0); }
+            else { alive_out[e] = (uint8_t)(here || there); code[e] = (uint8_t)(here && there ? 2 : 0); }
+        }
+    return 0;
+}

@@ -37,10 +37,11 @@ def snn_rows(nn, prune=0.0):
     return rowptr, col, shared
 
 
-def trim(rowptr, col, shared, ord):
-    """alive mask (uint8 per stored entry) after the sequential symmetric top-`ord` trim."""
+def trim(rowptr, col, shared, ord, alive=None):
+    """alive mask (uint8 per stored entry) after the sequential symmetric top-`ord` trim (ranked by `shared`, any
+    integer key), starting from `alive` (default: everything)."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
-    alive = np.ones(len(col), dtype=np.uint8)
+    alive = np.ones(len(col), dtype=np.uint8) if alive is None else np.ascontiguousarray(alive, dtype=np.uint8).copy()
     lib = _so.lib()
     lib.orc_snn_trim.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
                                  C.POINTER(C.c_uint8)]
@@ -58,3 +59,38 @@ def snn_graph(X, k, prune=0.0, ord=None):
     deg = np.bincount(rows[alive], minlength=len(rowptr) - 1)
     out_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
     return nn, out_ptr, col[alive], shared[alive]
+
+
+def snn_graph_variant(X, k, prune=0.0, ord=None, symmetric=True, enhance=None, bonus=2.0, ord2=None):
+    """The notebooks' optional chunks on top of the base construction: unsymmetric first trim, "enhance shared edges"
+    (mutual bonus / A + t(A)), second trim.  Returns (nn, rowptr, col, shared, code): the stored rows are the COLUMNS
+    of the result (entry e of row i with col[e] = r is A[r, i]); code 0 = w, 1 = w + bonus, 2 = w + w."""
+    lib = _so.lib()
+    nn = knn(X, k)
+    rowptr, col, shared = snn_rows(nn, prune)
+    n = len(rowptr) - 1
+    alive = np.ones(len(col), dtype=np.uint8)
+    if ord:
+        if symmetric:
+            alive = trim(rowptr, col, shared, ord)
+        else:
+            lib.orc_snn_trim_cols.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint8)]
+            lib.orc_snn_trim_cols(n, _p(rowptr, C.c_int64), _p(shared, C.c_int32), int(ord), _p(alive, C.c_uint8))
+    code = np.zeros(len(col), dtype=np.uint8)
+    if enhance is not None:
+        out = np.zeros_like(alive)
+        lib.orc_snn_enhance.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
+                                        C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+        lib.orc_snn_enhance(n, 1 if enhance == "mutual" else 2, _p(rowptr, C.c_int64), _p(col, C.c_int32),
+                            _p(alive, C.c_uint8), _p(out, C.c_uint8), _p(code, C.c_uint8))
+        alive = out
+    if ord2:
+        w = shared / (2.0 * k - shared)
+        val = np.where(code == 1, w + bonus, np.where(code == 2, w + w, w))
+        key = np.searchsorted(np.unique(val), val).astype(np.int32)       # ranks: the trim only compares
+        alive = trim(rowptr, col, key, ord2, alive=alive)
+    alive = alive.astype(bool)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    deg = np.bincount(rows[alive], minlength=n)
+    out_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    return nn, out_ptr, col[alive], shared[alive], code[alive]

@@ -26,6 +26,9 @@
 #include <vector>
 
 #include "../../include/mi_snn.h"
+#include <algorithm>
+#include <vector>
+
 #include "mi_sa_device.h"
 
 namespace mi_sa_impl {
@@ -355,6 +358,80 @@ __global__ void __launch_bounds__(kTrimParThreads) k_trim_par(int n, int ord, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The optional graph variants of the notebooks (Pbmc3k_general_data_preparation.Rmd:77-123, Kidney_data.Rmd:235-266)
+// ------------------------------------------------------------------------------------------------
+// The stored rows double as the COLUMNS of the (symmetric) SNN matrix: entry e of row i with col[e] = r is A[r, i].
+// "UNSYMMETRIC" trim (Rmd :77-83): column i keeps its `ord` heaviest entries (R's stable order(): heavier first, ties by
+// row index) and only column i is written, so the columns are independent: one wavefront per column, rank of an
+// entry = entries of the column that precede it in that order.
+__global__ void __launch_bounds__(256) k_trim_cols(int n, int ord, const int *__restrict__ rowptr,
+                                                   const int32_t *__restrict__ col, const int32_t *__restrict__ key,
+                                                   unsigned char *__restrict__ alive)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int b = rowptr[i], e1 = rowptr[i + 1];
+    if (e1 - b <= ord) return;
+    for (int e = b + lane; e < e1; e += 64) {
+        const int ke = key[e];
+        int rank = 0;
+        for (int f = b; f < e1; ++f) {                          // entries are stored ascending by row index
+            const int kf = key[f];
+            rank += (kf > ke || (kf == ke && f < e)) ? 1 : 0;
+        }
+        if (rank >= ord) alive[e] = 0;
+    }
+}
+
+// position of the mirror entry (row r, column i) of entry (row i, column r), or -1
+__device__ __forceinline__ int mirror_of(const int *__restrict__ rowptr, const int32_t *__restrict__ col, int r, int i)
+{
+    int lo = rowptr[r], hi = rowptr[r + 1] - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int cm = col[mid];
+        if (cm == i) return mid;
+        if (cm < i) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+// "Enhance shared edges".  mode 1 (Rmd :85-101, "Method 2"): an entry that is present in BOTH directions is marked
+// (code 1: the caller adds the bonus, + 2 * mutual resp. + mutual in the kidney notebook); the support is unchanged.
+// mode 2 (Rmd :103-113, A + t(A)): the support becomes the union of the two directions, an entry present in both is
+// marked code 2 (its weight doubles).
+__global__ void __launch_bounds__(256) k_enhance(int n, int mode, const int *__restrict__ rowptr,
+                                                 const int32_t *__restrict__ col,
+                                                 const unsigned char *__restrict__ alive_in,
+                                                 unsigned char *__restrict__ alive_out, unsigned char *__restrict__ code)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const int m = mirror_of(rowptr, col, col[e], i);
+        const bool here = alive_in[e] != 0, there = m >= 0 && alive_in[m] != 0;
+        if (mode == 1) {
+            alive_out[e] = here ? 1 : 0;
+            code[e] = (here && there) ? 1 : 0;
+        } else {
+            alive_out[e] = (here || there) ? 1 : 0;
+            code[e] = (here && there) ? 2 : 0;
+        }
+    }
+}
+
+// rank of an entry's enhanced weight among the values it can take (table built on the host in fp64 from s / (2k - s),
+// the bonus and the doubling): the trim kernels only compare
+__global__ void __launch_bounds__(256) k_make_keys(long long nnz, const int32_t *__restrict__ shared,
+                                                   const unsigned char *__restrict__ code,
+                                                   const int32_t *__restrict__ table, int32_t *__restrict__ key)
+{
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < nnz; e += (long long)gridDim.x * 256)
+        key[e] = table[shared[e] * 3 + (code ? code[e] : 0)];
+}
+
 __global__ void __launch_bounds__(256) k_compact_count(int n, const int *__restrict__ rowptr,
                                                        const unsigned char *__restrict__ alive, int *__restrict__ deg,
                                                        int *__restrict__ maxdeg)
@@ -371,13 +448,20 @@ __global__ void __launch_bounds__(256) k_compact_fill(int n, const int *__restri
                                                       const int32_t *__restrict__ shared,
                                                       const unsigned char *__restrict__ alive,
                                                       const int *__restrict__ out_ptr, int32_t *__restrict__ out_col,
-                                                      int32_t *__restrict__ out_shared)
+                                                      int32_t *__restrict__ out_shared,
+                                                      const unsigned char *__restrict__ code,
+                                                      unsigned char *__restrict__ out_code)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int o = out_ptr[i];
     for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
-        if (alive[e]) { out_col[o] = col[e]; out_shared[o] = shared[e]; ++o; }
+        if (alive[e]) {
+            out_col[o] = col[e];
+            out_shared[o] = shared[e];
+            if (out_code) out_code[o] = code ? code[e] : (unsigned char)0;
+            ++o;
+        }
 }
 
 template <int DP>
@@ -404,6 +488,8 @@ struct mi_snn_graph {
     int32_t *d_nn = nullptr;
     int *d_ptr = nullptr;            // final rowptr (n+1)
     int32_t *d_col = nullptr, *d_shared = nullptr;
+    unsigned char *d_code = nullptr;  // per entry: 0 plain, 1 present in both directions (mutual bonus), 2 doubled (A + t(A))
+    int flags = 0, ord2 = 0;
 };
 
 extern "C" {
@@ -412,7 +498,7 @@ int mi_snn_destroy(mi_snn_graph *g)
 {
     if (!g) return MI_OK;
     (void)hipSetDevice(g->device);
-    void *bufs[] = {g->d_nn, g->d_ptr, g->d_col, g->d_shared};
+    void *bufs[] = {g->d_nn, g->d_ptr, g->d_col, g->d_shared, g->d_code};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete g;
@@ -421,7 +507,21 @@ int mi_snn_destroy(mi_snn_graph *g)
 
 int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int ord, int device, mi_snn_graph **out)
 {
+    return mi_snn_build_ex_f32(X, n, dim, k, prune, ord, 0u, 0.0, 0, device, out);
+}
+
+int mi_snn_build_ex_f32(const float *X, int n, int dim, int k, double prune, int ord, uint32_t flags, double bonus,
+                        int ord2, int device, mi_snn_graph **out)
+{
     if (!X || !out) return fail(MI_EINVAL, "NULL argument");
+    if (flags & ~(uint32_t)(MI_SNN_TRIM_UNSYMMETRIC | MI_SNN_ENHANCE_MUTUAL | MI_SNN_ENHANCE_SUM))
+        return fail(MI_EINVAL, "unknown flags 0x%x", flags);
+    if ((flags & MI_SNN_ENHANCE_MUTUAL) && (flags & MI_SNN_ENHANCE_SUM))
+        return fail(MI_EINVAL, "choose one enhancement: mutual bonus or A + t(A)");
+    if ((flags & MI_SNN_TRIM_UNSYMMETRIC) && ord <= 0) return fail(MI_EINVAL, "the unsymmetric trim needs ord > 0");
+    if (ord2 > 0 && (flags & MI_SNN_TRIM_UNSYMMETRIC) && !(flags & MI_SNN_ENHANCE_SUM))
+        return fail(MI_EUNSUPPORTED, "the second trim is built for symmetric matrices (symmetric first trim, or A + t(A))");
+    if (!(bonus >= 0.0)) return fail(MI_EINVAL, "bonus must be >= 0");
     if (n < 2 || dim < 1 || dim > 64) return fail(MI_EINVAL, "need n >= 2 and 1 <= dim <= 64 (got n=%d dim=%d)", n, dim);
     if (k < 2 || k > 64 || k > n) return fail(MI_EINVAL, "need 2 <= k <= min(64, n) (got k=%d)", k);
     if (!(prune >= 0.0)) return fail(MI_EINVAL, "prune must be >= 0");
@@ -433,15 +533,16 @@ int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int or
     HIP_TRY(hipSetDevice(device));
     mi_snn_graph *g = new (std::nothrow) mi_snn_graph();
     if (!g) return fail(MI_ENOMEM, "out of host memory");
-    g->n = n; g->dim = dim; g->k = k; g->ord = ord; g->device = device;
+    g->n = n; g->dim = dim; g->k = k; g->ord = ord; g->device = device; g->flags = (int)flags; g->ord2 = ord2;
 
     float *dX = nullptr;
     int *d_cnt = nullptr, *d_rn_ptr = nullptr, *d_cursor = nullptr, *d_deg = nullptr, *d_ptr0 = nullptr, *d_err = nullptr;
     int32_t *d_rn_idx = nullptr, *d_col0 = nullptr, *d_sh0 = nullptr;
-    unsigned char *d_alive = nullptr;
+    unsigned char *d_alive = nullptr, *d_alive2 = nullptr, *d_code0 = nullptr;
+    int32_t *d_key = nullptr, *d_table = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = nullptr;
-    int rc = [&]() -> int {
+    int rc = guarded([&]() -> int {
         int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -500,30 +601,77 @@ int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int or
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[2], st));
 
-        // S4: the sequential symmetric trim, S5: compaction
-        if (ord > 0 && !getenv("MI_SNN_TRIM_SEQUENTIAL")) {
-            // many columns in flight (k_trim_par); the sequential kernel is the fallback should a dependency
-            // wait ever hit its bound (MI_SNN_TRIM_SEQUENTIAL=1 forces it)
-            unsigned int *d_tctrl = nullptr, *d_done = nullptr;
-            HIP_TRY(hipMalloc((void **)&d_tctrl, 2 * sizeof(unsigned int)));
-            HIP_TRY(hipMalloc((void **)&d_done, (size_t)n * sizeof(unsigned int)));
-            HIP_TRY(hipMemsetAsync(d_tctrl, 0, 2 * sizeof(unsigned int), st));
-            HIP_TRY(hipMemsetAsync(d_done, 0, (size_t)n * sizeof(unsigned int), st));
-            const int tgrid = cus * 2;
-            hipLaunchKernelGGL(k_trim_par, dim3(tgrid), dim3(kTrimParThreads), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0,
-                               d_alive, d_tctrl, d_done);
-            unsigned int terr = 0;
-            HIP_TRY(hipMemcpyAsync(&terr, d_tctrl + 1, sizeof terr, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            (void)hipFree(d_tctrl);
-            (void)hipFree(d_done);
-            if (terr) {
-                fprintf(stderr, "mi_snn: parallel trim hit a wait bound; redoing sequentially\n");
-                HIP_TRY(hipMemsetAsync(d_alive, 1, (size_t)(nnz0 > 0 ? nnz0 : 1), st));
-                hipLaunchKernelGGL(k_trim, dim3(1), dim3(kTrimThreads), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0, d_alive);
+        // S4: trim(s) and enhancement, S5: compaction
+        // the sequential symmetric trim on `keys` (shared counts, or ranks of the enhanced weights) with degree cap `cap`
+        auto trim_symmetric = [&](const int32_t *keys, int cap) -> int {
+            if (!getenv("MI_SNN_TRIM_SEQUENTIAL")) {
+                // many columns in flight (k_trim_par); the sequential kernel is the fallback should a dependency
+                // wait ever hit its bound (MI_SNN_TRIM_SEQUENTIAL=1 forces it)
+                unsigned int *d_tctrl = nullptr, *d_done = nullptr;
+                unsigned char *d_save = nullptr;
+                HIP_TRY(hipMalloc((void **)&d_tctrl, 2 * sizeof(unsigned int)));
+                HIP_TRY(hipMalloc((void **)&d_done, (size_t)n * sizeof(unsigned int)));
+                HIP_TRY(hipMalloc((void **)&d_save, (size_t)(nnz0 > 0 ? nnz0 : 1)));
+                HIP_TRY(hipMemcpyAsync(d_save, d_alive, (size_t)(nnz0 > 0 ? nnz0 : 1), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemsetAsync(d_tctrl, 0, 2 * sizeof(unsigned int), st));
+                HIP_TRY(hipMemsetAsync(d_done, 0, (size_t)n * sizeof(unsigned int), st));
+                const int tgrid = cus * 2;
+                hipLaunchKernelGGL(k_trim_par, dim3(tgrid), dim3(kTrimParThreads), 0, st, n, cap, (const int *)d_ptr0, d_col0, keys,
+                                   d_alive, d_tctrl, d_done);
+                unsigned int terr = 0;
+                HIP_TRY(hipMemcpyAsync(&terr, d_tctrl + 1, sizeof terr, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                (void)hipFree(d_tctrl);
+                (void)hipFree(d_done);
+                if (terr) {
+                    fprintf(stderr, "mi_snn: parallel trim hit a wait bound; redoing sequentially\n");
+                    HIP_TRY(hipMemcpyAsync(d_alive, d_save, (size_t)(nnz0 > 0 ? nnz0 : 1), hipMemcpyDeviceToDevice, st));
+                    hipLaunchKernelGGL(k_trim, dim3(1), dim3(kTrimThreads), 0, st, n, cap, (const int *)d_ptr0, d_col0, keys, d_alive);
+                    HIP_TRY(hipStreamSynchronize(st));
+                }
+                (void)hipFree(d_save);
+            } else {
+                hipLaunchKernelGGL(k_trim, dim3(1), dim3(kTrimThreads), 0, st, n, cap, (const int *)d_ptr0, d_col0, keys, d_alive);
             }
+            HIP_TRY(hipGetLastError());
+            return MI_OK;
+        };
+        if (ord > 0 && (flags & MI_SNN_TRIM_UNSYMMETRIC)) {
+            hipLaunchKernelGGL(k_trim_cols, dim3((n + 3) / 4), dim3(256), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0, d_alive);
+            HIP_TRY(hipGetLastError());
         } else if (ord > 0) {
-            hipLaunchKernelGGL(k_trim, dim3(1), dim3(kTrimThreads), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0, d_alive);
+            const int r3 = trim_symmetric(d_sh0, ord);
+            if (r3) return r3;
+        }
+        if (flags & (MI_SNN_ENHANCE_MUTUAL | MI_SNN_ENHANCE_SUM)) {
+            HIP_TRY(hipMalloc((void **)&d_alive2, (size_t)(nnz0 > 0 ? nnz0 : 1)));
+            HIP_TRY(hipMalloc((void **)&d_code0, (size_t)(nnz0 > 0 ? nnz0 : 1)));
+            hipLaunchKernelGGL(k_enhance, dim3((n + 255) / 256), dim3(256), 0, st, n, (flags & MI_SNN_ENHANCE_MUTUAL) ? 1 : 2,
+                               (const int *)d_ptr0, d_col0, d_alive, d_alive2, d_code0);
+            HIP_TRY(hipGetLastError());
+            std::swap(d_alive, d_alive2);
+        }
+        if (ord2 > 0) {
+            // ranks of the values an entry can hold, in fp64 as R holds them: w = s / (2k - s), w + bonus, w + w
+            std::vector<double> vals;
+            for (int sct = 0; sct <= k; ++sct) {
+                const double w = sct == 0 ? 0.0 : (double)sct / (2.0 * k - (double)sct);
+                vals.push_back(w); vals.push_back(w + bonus); vals.push_back(w + w);
+            }
+            std::vector<double> uniq(vals);
+            std::sort(uniq.begin(), uniq.end());
+            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            std::vector<int32_t> table(vals.size());
+            for (size_t q = 0; q < vals.size(); ++q)
+                table[q] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), vals[q]) - uniq.begin());
+            HIP_TRY(hipMalloc((void **)&d_table, table.size() * sizeof(int32_t)));
+            HIP_TRY(hipMalloc((void **)&d_key, (size_t)(nnz0 > 0 ? nnz0 : 1) * sizeof(int32_t)));
+            HIP_TRY(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_make_keys, dim3(1024), dim3(256), 0, st, (long long)nnz0, d_sh0, d_code0, d_table, d_key);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));                   // (table goes out of scope)
+            const int r3 = trim_symmetric(d_key, ord2);
+            if (r3) return r3;
         }
         HIP_TRY(hipMemsetAsync(d_err + 1, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_compact_count, dim3((n + 255) / 256), dim3(256), 0, st, n, (const int *)d_ptr0, d_alive, d_deg, d_err + 1);
@@ -536,8 +684,9 @@ int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int or
         g->nnz = nnz1;
         HIP_TRY(hipMalloc((void **)&g->d_col, (size_t)(nnz1 > 0 ? nnz1 : 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&g->d_shared, (size_t)(nnz1 > 0 ? nnz1 : 1) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&g->d_code, (size_t)(nnz1 > 0 ? nnz1 : 1)));
         hipLaunchKernelGGL(k_compact_fill, dim3((n + 255) / 256), dim3(256), 0, st, n, (const int *)d_ptr0, d_col0, d_sh0, d_alive,
-                           (const int *)g->d_ptr, g->d_col, g->d_shared);
+                           (const int *)g->d_ptr, g->d_col, g->d_shared, (const unsigned char *)d_code0, g->d_code);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[3], st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -545,8 +694,8 @@ int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int or
         HIP_TRY(hipEventElapsedTime(&g->ms_snn, ev[1], ev[2]));
         HIP_TRY(hipEventElapsedTime(&g->ms_trim, ev[2], ev[3]));
         return MI_OK;
-    }();
-    void *tmp[] = {dX, d_cnt, d_rn_ptr, d_cursor, d_rn_idx, d_deg, d_ptr0, d_err, d_col0, d_sh0, d_alive};
+    });
+    void *tmp[] = {dX, d_cnt, d_rn_ptr, d_cursor, d_rn_idx, d_deg, d_ptr0, d_err, d_col0, d_sh0, d_alive, d_alive2, d_code0, d_key, d_table};
     for (void *b : tmp)
         if (b) (void)hipFree(b);
     for (auto &e : ev)
@@ -583,6 +732,14 @@ int mi_snn_fetch(mi_snn_graph *g, int32_t *nn, int64_t *rowptr, int32_t *col, in
     }
     if (col && g->nnz) HIP_TRY(hipMemcpy(col, g->d_col, (size_t)g->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (shared && g->nnz) HIP_TRY(hipMemcpy(shared, g->d_shared, (size_t)g->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_snn_fetch_codes(mi_snn_graph *g, uint8_t *code)
+{
+    if (!g || !code) return fail(MI_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(g->device));
+    if (g->nnz) HIP_TRY(hipMemcpy(code, g->d_code, (size_t)g->nnz, hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

@@ -62,13 +62,17 @@ def _knn_exact(X: np.ndarray, k: int, block: int = 2048) -> np.ndarray:
     return out
 
 
-def snn_from_points(X: np.ndarray, k: int, ord: Optional[int]) -> np.ndarray:
-    """Dense symmetric SNN weight matrix (zero diagonal), trimmed to degree <= ``ord`` if given.
+def snn_from_points(X: np.ndarray, k: int, ord: Optional[int], symmetric: bool = True,
+                    enhance: Optional[str] = None, bonus: float = 2.0, ord2: Optional[int] = None) -> np.ndarray:
+    """Dense SNN weight matrix (zero diagonal), trimmed to degree <= ``ord`` if given.
 
     A LITERAL dense numpy restatement of the R lines (O(n^2) memory, Python loop over columns): it generates
     the small synthetic workloads of bench.py / the tests and pins oracle/snn_oracle.c.  It is not a fallback
     of the product path: graphs are BUILT by ``snn.build_snn`` (GPU, csrc/snn_kernels.hip), which raises when
-    the HIP library is missing."""
+    the HIP library is missing.  The optional arguments are the notebooks' optional chunks
+    (`Pbmc3k_general_data_preparation.Rmd:77-123`): ``symmetric=False`` the UNSYMMETRIC first trim (:77-83),
+    ``enhance="mutual"`` Method 2 (:85-101, ``+ bonus * mutual``), ``enhance="sum"`` ``A + t(A)`` (:103-113),
+    ``ord2`` the second trim (:116-123)."""
     n = X.shape[0]
     nn = _knn_exact(X, k)
     M = np.zeros((n, n), dtype=np.float32)
@@ -76,16 +80,53 @@ def snn_from_points(X: np.ndarray, k: int, ord: Optional[int]) -> np.ndarray:
     shared = (M @ M.T).astype(np.int64)                        # |N(i) & N(j)|
     snn = np.where(shared > 0, shared / (2.0 * k - shared), 0.0)
     np.fill_diagonal(snn, 0.0)                                 # snn - diag(n)  (Rmd :72)
-    if ord is not None:
+
+    def trim_symmetric(cap):
         # Rmd :75-79 -- for i in 1..n: to_delete = order(snn[,i], decreasing=TRUE)[(ord+1):n];
         # zero column i and row i there.  Sequential and in place; R's order() is stable.
         for i in range(n):
             colv = snn[:, i]
             order = np.argsort(-colv, kind="stable")
-            to_delete = order[ord:]
+            to_delete = order[cap:]
             snn[to_delete, i] = 0.0
             snn[i, to_delete] = 0.0
+
+    if ord is not None and symmetric:
+        trim_symmetric(ord)
+    elif ord is not None:
+        for i in range(n):                                     # :77-83 -- the column only
+            to_delete = np.argsort(-snn[:, i], kind="stable")[ord:]
+            snn[to_delete, i] = 0.0
+    if enhance == "mutual":                                    # :85-101
+        mutual = (snn != 0) & (snn.T != 0)
+        snn = snn + bonus * mutual
+    elif enhance == "sum":                                     # :103-113
+        snn = snn + snn.T
+    elif enhance is not None:
+        raise ValueError("enhance must be None, 'mutual' or 'sum'")
+    if ord2 is not None:                                       # :116-123
+        trim_symmetric(ord2)
     return snn
+
+
+def edges_from_matrix(A: np.ndarray):
+    """``(eu, ev, w)`` of ``nx.from_numpy_matrix(A)`` for a possibly ASYMMETRIC matrix, in ``G.edges`` order: the
+    undirected edge {u, v}, u < v, exists when either entry is non-zero; it carries ``A[v, u]`` when that is non-zero
+    (row v is visited after row u and overwrites the attribute), else ``A[u, v]``; node u reports first the
+    neighbours v > u it met in its own row, then those it only learnt from their rows."""
+    n = A.shape[0]
+    up = np.triu(A, 1)
+    lo = np.tril(A, -1).T                                      # lo[u, v] = A[v, u], u < v
+    own = up != 0
+    other = (~own) & (lo != 0)
+    eu, ev, w = [], [], []
+    for u in range(n):
+        for mask in (own[u], other[u]):
+            vs = np.nonzero(mask)[0]
+            eu.extend([u] * len(vs))
+            ev.extend(vs.tolist())
+            w.extend(np.where(lo[u, vs] != 0, lo[u, vs], up[u, vs]).tolist())
+    return np.asarray(eu, dtype=np.int32), np.asarray(ev, dtype=np.int32), np.asarray(w, dtype=np.float64)
 
 
 def synthetic_snn(n: int = 2638, k: int = 5, dim: int = 15, ord: Optional[int] = 15,

@@ -27,6 +27,41 @@ def test_graph_equals_oracle(n, k, ord_, dim, prune):
     assert g.max_degree == int(np.diff(rowptr).max())
 
 
+@pytest.mark.parametrize("kw", [dict(symmetric=False), dict(enhance="mutual"), dict(enhance="mutual", mutual_bonus=1.0, symmetric=False),
+                                dict(enhance="sum"), dict(enhance="sum", symmetric=False), dict(enhance="mutual", ord2=9),
+                                dict(enhance="sum", symmetric=False, ord2=7), dict(ord2=5)])
+@pytest.mark.parametrize("n,k,ord_,dim", [(300, 5, 15, 15), (2638, 5, 15, 15), (900, 10, 12, 30)])
+def test_variant_graphs_equal_oracle(n, k, ord_, dim, kw):
+    """The notebooks' optional chunks on the GPU (unsymmetric trim, mutual bonus / A + t(A), second trim:
+    Pbmc3k_general_data_preparation.Rmd:77-123, Kidney_data.Rmd:235-266) against oracle/snn_oracle.c: structure, shared
+    counts and weight codes bit for bit; the exported edge list equals graphs.edges_from_matrix of the dense matrix."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    X = cloud(n, dim, seed=5 * n + k)
+    g = snn.build_snn(X, k, 0.0, ord_, **kw)
+    nn, rowptr, col, shared, code = sn.snn_graph_variant(X, k, 0.0, ord_, kw.get("symmetric", True), kw.get("enhance"),
+                                                        kw.get("mutual_bonus", 2.0), kw.get("ord2"))
+    assert np.array_equal(g.rowptr, rowptr) and np.array_equal(g.col, col)
+    assert np.array_equal(g.shared, shared) and np.array_equal(g.code, code)
+    if n <= 300:
+        A = np.zeros((n, n))
+        A[g.col, np.repeat(np.arange(n), np.diff(g.rowptr))] = g.weights
+        eu, ev, w = graphs.edges_from_matrix(A)
+        _, gu, gv, gw = g.edge_list()
+        assert np.array_equal(gu, eu) and np.array_equal(gv, ev) and np.array_equal(gw, w)
+        m = models.build_bqm_qubo(g.to_graph(), 0.05)              # the variant graph feeds the clustering model
+        assert m.num_variables == n
+
+
+def test_variant_argument_validation():
+    X = cloud(100, 3, seed=0)
+    with pytest.raises(_lib.MiSaError):
+        snn.build_snn(X, 5, 0.0, 10, symmetric=False, enhance="mutual", ord2=5)      # second trim needs a symmetric matrix
+    with pytest.raises(_lib.MiSaError):
+        snn.build_snn(X, 5, 0.0, None, symmetric=False)                              # unsymmetric trim needs ord
+    with pytest.raises(ValueError):
+        snn.build_snn(X, 5, 0.0, 10, enhance="both")
+
+
 def test_duplicate_points_and_size_independent_properties():
     """Ties (duplicated points) resolve by index as in the oracle; at n = 20000 the graph is checked through
     properties: symmetric, zero diagonal, degree <= ord, s in [1, k], every row ascending."""

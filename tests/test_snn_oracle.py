@@ -38,3 +38,51 @@ def test_prune_drops_light_edges_and_ties_keep_index_order():
     # duplicate points: equal distances are ordered by index
     Y = np.zeros((5, 2), dtype=np.float32)
     assert sn.knn(Y, 3).tolist() == [[0, 1, 2], [1, 0, 2], [2, 0, 1], [3, 0, 1], [4, 0, 1]]
+
+
+VARIANTS = [dict(symmetric=False), dict(enhance="mutual"), dict(enhance="mutual", bonus=1.0, symmetric=False),
+            dict(enhance="sum"), dict(enhance="sum", symmetric=False), dict(enhance="mutual", ord2=9),
+            dict(enhance="sum", symmetric=False, ord2=7), dict(ord2=5), dict(enhance="sum", ord2=12)]
+
+
+def _dense_from_variant(n, k, rowptr, col, shared, code, bonus):
+    """A[r, i] from the stored rows (= columns) of a variant graph, weights in fp64 as R computes them."""
+    w = shared / (2.0 * k - shared)
+    w = np.where(code == 1, w + bonus, np.where(code == 2, w + w, w))
+    A = np.zeros((n, n))
+    A[col, np.repeat(np.arange(n), np.diff(rowptr))] = w
+    return A
+
+
+@pytest.mark.parametrize("kw", VARIANTS)
+@pytest.mark.parametrize("n,k,ord_,dim", [(300, 5, 15, 15), (257, 8, 6, 4)])
+def test_variant_chunks_equal_their_dense_restatement(n, k, ord_, dim, kw):
+    """The notebooks' optional chunks (unsymmetric trim, the two enhancements, the second trim) in the oracle against
+    the literal dense restatement of Pbmc3k_general_data_preparation.Rmd:77-123 -- bit-equal fp64 matrices."""
+    X = cloud(n, dim, seed=3 * n + k)
+    bonus = kw.get("bonus", 2.0)
+    nn, rowptr, col, shared, code = sn.snn_graph_variant(X, k, 0.0, ord_, kw.get("symmetric", True), kw.get("enhance"),
+                                                        bonus, kw.get("ord2"))
+    dense = graphs.snn_from_points(X.astype(np.float64), k, ord_, symmetric=kw.get("symmetric", True),
+                                   enhance=kw.get("enhance"), bonus=bonus, ord2=kw.get("ord2"))
+    A = _dense_from_variant(n, k, rowptr, col, shared, code, bonus)
+    assert np.array_equal(A, dense)
+    if kw.get("symmetric", True) or kw.get("enhance") == "sum":
+        assert np.array_equal(A, A.T)
+    else:
+        assert not np.array_equal(A, A.T)                       # the unsymmetric trim really breaks the symmetry
+    if kw.get("ord2"):
+        assert (A != 0).sum(axis=0).max() <= kw["ord2"]
+
+
+def test_edge_list_of_an_asymmetric_matrix_is_what_networkx_builds():
+    """graphs.edges_from_matrix == nx.from_numpy_array(A) + G.edges(data=True) (the notebooks' export:
+    Pbmc3k_general_data_preparation.Rmd:145 `nx.from_numpy_matrix`), order and weights, for an asymmetric matrix."""
+    import networkx as nx
+    X = cloud(120, 6, seed=9)
+    A = graphs.snn_from_points(X.astype(np.float64), 6, 5, symmetric=False, enhance="mutual")
+    assert not np.array_equal(A, A.T)
+    G = nx.from_numpy_array(A)
+    want = [(u, v, d["weight"]) for u, v, d in G.edges(data=True)]
+    eu, ev, w = graphs.edges_from_matrix(A)
+    assert [(int(a), int(b), float(c)) for a, b, c in zip(eu, ev, w)] == want
