@@ -13,7 +13,11 @@ d, replicas, sweeps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 outp = sys.argv[4] if len(sys.argv) > 4 else os.path.join(root, "profiles", "r02_k2_binding.json")
 vals, kernel, dur = {}, None, []
 for f in sorted(glob.glob(os.path.join(d, "p*.csv"))):
-    for r in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    last = max(int(r["Dispatch_Id"]) for r in rows)            # several anneals per pass: the last one (warm)
+    for r in rows:
+        if int(r["Dispatch_Id"]) != last:
+            continue
         vals[r["Counter_Name"]] = float(r["Counter_Value"])
         kernel = r["Kernel_Name"]
         dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
@@ -27,7 +31,7 @@ out = {
     "l2": {"request_bytes": l2_bytes, "GBps": l2_bytes / (ms * 1e-3) / 1e9, "peak_GBps": 34500.0,
            "frac": l2_bytes / (ms * 1e-3) / 1e9 / 34500.0, "hit_rate": vals["TCC_HIT_sum"] / vals["TCC_REQ_sum"]},
     "lds": {"busy_frac": vals["SQ_LDS_IDX_ACTIVE"] / (256.0 * cycles),
-            "bank_conflict_share": vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]},
+            "bank_conflict_share": vals["SQ_LDS_BANK_CONFLICT"] / max(vals["SQ_LDS_IDX_ACTIVE"], 1.0)},
     "valu": {"wave_instructions": vals["SQ_INSTS_VALU"],
              "issue_frac_at_2_cycles": vals["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles),
              "issue_frac_at_3p1_cycles": vals["SQ_INSTS_VALU"] * 3.1 / (1024.0 * cycles)},
@@ -36,7 +40,7 @@ out = {
     "waves": {"active_issuing": vals["SQ_ACTIVE_INST_ANY"] / vals["SQ_WAVE_CYCLES"],
               "stalled_on_issue": vals["SQ_WAIT_INST_ANY"] / vals["SQ_WAVE_CYCLES"],
               "parked_on_waitcnt": vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"]},
-    "source": "%s/p1..p6.csv (scripts/pmc_k2.sh)" % os.path.relpath(d, root),
+    "source": "%s/p*.csv (scripts/pmc_k2.sh / pmc_k3.sh)" % os.path.relpath(d, root),
 }
 json.dump(out, open(outp, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -11,7 +11,7 @@ m, Qs, betas, _, graph = bench.build_workload()
 pm = models.build_dqm_potts(graph, 8, 0.005)
 R, S, n = int(os.environ.get("K3_R", "4096")), 200, 2638
 b = models.make_beta_schedule(S, default_potts_beta_range(pm))
-for order in ("slots", None):
+for order in (("slots",) if os.environ.get("K3_ONLY_SLOTS") else ("slots", None)):
     with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(np.float32), float(np.float32(pm.c_pair)), n, 8,
                            lin_offset=pm.lin_offset, order=order) as p:
         for _ in range(2):

@@ -20,7 +20,7 @@ out = {"replicas": int(sys.argv[2]), "sweeps": int(sys.argv[3]), "launches": lau
        "kernel": KERNEL,
        "fetch_bytes_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
        "hbm_bytes_per_step": (fetch + write) * launches,
-       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0; "
+       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1; "
                  "per launch = mean over the anneal launches of the step; FETCH_SIZE KiB x 1024 x 2 (gfx950 "
                  "half-count) + WRITE_SIZE KiB x 1024"}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
