@@ -81,28 +81,20 @@ class BinaryQuadraticModel:
                                          lagrange_multiplier: float, label: str,
                                          constant: int = 0, lb: float = 0, ub: float = 0,
                                          cross_zero: bool = False, penalization_method="slack"):
-        """``lb <= sum_i a_i x_i + constant <= ub`` as the penalty
-        ``lagrange * (sum_i a_i x_i + constant - lb - sum_b c_b s_b)^2`` with binary slack variables
-        ``slack_<label>_<b>`` whose coefficients (1, 2, 4, ..., remainder) span ``[0, ub - lb]``
-        (dimod's construction; BQM_clustering.py:376-380).  Returns the slack terms."""
+        """``lb <= sum_i a_i x_i + constant <= ub`` the way dimod adds it (BQM_clustering.py:376-380 calls it with
+        ``lb = size_limit``, ``ub = n / 6`` -- fractional -- and ``lagrange_multiplier = gamma``): binary slack variables
+        ``slack_<label>_<j>`` with POSITIVE coefficients spanning ``[0, int(ub_c - lb_c)]`` and the equality penalty
+        ``lagrange * (sum_i a_i x_i + sum_j c_j s_j - ub_c)^2`` with ``ub_c = min(sum of positive a_i, ub - constant)``
+        kept as it is (not floored).  See :func:`inequality_slack`.  Returns the slack terms."""
         if self.vartype != "BINARY":
             raise ValueError("inequality constraints are supported for BINARY models")
         terms = list(terms)
-        if int(ub) < int(np.ceil(lb)):
-            raise ValueError("infeasible constraint: ub < lb")
-        lb_c, ub_c = int(np.ceil(lb)), int(np.floor(ub))
-        span = ub_c - lb_c
-        coeffs: List[int] = []
-        b = 1
-        rem = span
-        while rem > 0:
-            c = min(b, rem)
-            coeffs.append(c)
-            rem -= c
-            b *= 2
-        slack = [("slack_%s_%d" % (label, i), -c) for i, c in enumerate(coeffs)]
+        coeffs, ub_c = inequality_slack([a for _, a in terms], lb, ub, constant, label)
+        if coeffs is None:
+            return []                                            # feasible for every state: dimod adds nothing
+        slack = [("slack_%s_%d" % (label, j), c) for j, c in enumerate(coeffs)]
         allterms = terms + slack
-        const = constant - lb_c
+        const = -ub_c
         lam = float(lagrange_multiplier)
         # lam * (sum a z + const)^2, z binary  => z^2 = z
         for k, (v, a) in enumerate(allterms):
@@ -111,6 +103,33 @@ class BinaryQuadraticModel:
                 self.add_quadratic(v, u, lam * 2.0 * a * a2)
         self.offset += lam * const * const
         return slack
+
+
+def inequality_slack(coefficients, lb, ub, constant=0, label="constraint"):
+    """Slack coefficients and right-hand side of dimod's ``add_linear_inequality_constraint`` [upstream dimod >= 0.10,
+    restated from its published source, not importable here: parity unpinned]:
+    ``ub_c = min(sum of positive coefficients, ub - constant)``, ``lb_c = max(sum of negative coefficients, lb - constant)``;
+    nothing to add when every state is feasible (returns ``(None, ub_c)``); ``ValueError`` when ``ub_c < lb_c``;
+    ``slack_upper_bound = int(ub_c - lb_c)``; no slack when that is 0 (a plain equality at ``ub_c``); else coefficients
+    ``2^j`` for ``j < floor(log2(slack_upper_bound))`` plus the remainder ``slack_upper_bound - 2^floor(log2) + 1``.
+    The penalty is ``lagrange * (terms + slack - ub_c)^2`` -- with a fractional ``ub`` (the reference passes ``n / 6``) its
+    minimum over the slack is not zero."""
+    pos = float(sum(a for a in coefficients if a > 0))
+    neg = float(sum(a for a in coefficients if a < 0))
+    ub_c = min(pos, float(ub) - constant)
+    lb_c = max(neg, float(lb) - constant)
+    if pos <= ub_c and neg >= lb_c:
+        return None, ub_c
+    if ub_c < lb_c:
+        raise ValueError("The given constraint (%s) is infeasible with any value for state variables." % label)
+    slack_upper_bound = int(ub_c - lb_c)
+    if slack_upper_bound == 0:
+        return [], ub_c
+    num_slack = int(np.floor(np.log2(slack_upper_bound)))
+    coeffs = [2 ** j for j in range(num_slack)]
+    if slack_upper_bound - 2 ** num_slack >= 0:
+        coeffs.append(slack_upper_bound - 2 ** num_slack + 1)
+    return coeffs, ub_c
 
 
 class DiscreteQuadraticModel:

@@ -695,7 +695,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "chunk_sweeps") && value >= 0) { p->opt_chunk_sweeps = (int)value; return MI_OK; }
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "debug")) { p->opt_debug = (int)value; return MI_OK; }
-    if (!strcmp(key, "k2_waves") && value >= 0 && value <= 16) { p->opt_k2_waves = (int)value; return MI_OK; }
+    if (!strcmp(key, "k2_waves") && ((value >= 0 && value <= 16) || value == 99)) { p->opt_k2_waves = (int)value; return MI_OK; }   // (99: K3 keeps its serial move loop -- A/B timing)
     if (!strcmp(key, "k2_pair") && value >= 0 && value <= 2) { p->opt_k2_pair = (int)value; return MI_OK; }
     if (!strcmp(key, "min_cluster_size") && value >= 0) {
         if (p->kind != MI_KIND_POTTS_CSR) return fail(MI_EINVAL, "min_cluster_size applies to Potts problems");

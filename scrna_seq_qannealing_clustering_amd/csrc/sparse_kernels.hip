@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             };
             // the two wave-uniform switches select one of four straight-line copies of the loop (inside it they
             // would be a ladder of taken branches on the serial path)
-            if (has_in == 0ull && K <= 16) {
+            if (has_in == 0ull && K <= 16 && a.waves_override != 99) {
                 // ---- no variable of this slot has a neighbour inside it (every slot under the slot-independent
                 // order): a lane's decision depends on the movers below it only through the sizes of ITS two clusters.
                 // As in K2, the accept mask of the sequential sweep is the one fixed point of "evaluate every lane

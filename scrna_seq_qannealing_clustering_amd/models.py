@@ -375,35 +375,32 @@ def permute_csr(rowptr, col, val, perm):
 def add_size_window_penalty(model: QuboModel, lb: float, ub: float, lagrange_multiplier: float,
                             slack_prefix: str = "slack_c1_constraint_") -> QuboModel:
     """Penalty form of ``bqm.add_linear_inequality_constraint([(x_i, 1)...], lb, ub, lagrange)``
-    (BQM_clustering.py:373-380): adds binary slack variables ``t_b`` with ``lb + sum_b c_b t_b``
-    spanning ``[lb, floor(ub)]`` and the energy ``lagrange * (sum_i x_i - lb - sum_b c_b t_b)^2``.
-    Returned as a dense-backed QuboModel over ``variables + slack`` (small O(log n) growth)."""
+    (BQM_clustering.py:373-380) in dimod's construction (:func:`bqm.inequality_slack`, shared with the
+    ``BinaryQuadraticModel`` look-alike): binary slack variables ``t_j`` with positive coefficients ``c_j`` spanning
+    ``[0, int(ub - lb)]`` and the energy ``lagrange * (sum_i x_i + sum_j c_j t_j - ub)^2`` with ``ub`` kept fractional
+    (the reference passes ``n / 6``: for n = 256, lb = 40 the sizes 41-43 cost the minimum ``lagrange / 9``, not zero).
+    ``ValueError`` when ``ub < lb``.  Returned as a dense-backed QuboModel over ``variables + slack``."""
+    from .bqm import inequality_slack
     n = model.num_variables
-    ub_c = int(np.floor(ub))
-    lb_c = int(np.ceil(lb))
-    span = max(ub_c - lb_c, 0)
-    coeffs: List[int] = []
-    rem = span
-    b = 1
-    while rem > 0:
-        c = min(b, rem)
-        coeffs.append(c)
-        rem -= c
-        b *= 2
+    coeffs, ub_c = inequality_slack([1] * n, lb, ub, 0, slack_prefix.rstrip("_"))
+    if coeffs is None:
+        coeffs, lam = [], 0.0                                   # feasible for every state: nothing is added
+    else:
+        lam = float(lagrange_multiplier)
+    lb_c = max(0.0, float(lb))
     ns = len(coeffs)
-    a = np.concatenate([np.ones(n), -np.asarray(coeffs, dtype=np.float64)])   # sum a_i z_i - lb
+    a = np.concatenate([np.ones(n), np.asarray(coeffs, dtype=np.float64)])     # sum a_i z_i - ub_c
     N = n + ns
     Qs = np.zeros((N, N), dtype=np.float64)
     Qs[:n, :n] = model.dense_Qs()
-    lam = float(lagrange_multiplier)
-    # lam (a.z - lb)^2 = lam [ sum_i a_i^2 z_i + 2 sum_{i<j} a_i a_j z_i z_j - 2 lb a.z + lb^2 ]
+    # lam (a.z - ub_c)^2 = lam [ sum_i a_i^2 z_i + 2 sum_{i<j} a_i a_j z_i z_j - 2 ub_c a.z + ub_c^2 ]
     outer = lam * np.outer(a, a)
     Qs += outer - np.diag(np.diag(outer))
-    Qs[np.arange(N), np.arange(N)] += lam * (a * a - 2.0 * lb_c * a)
+    Qs[np.arange(N), np.arange(N)] += lam * (a * a - 2.0 * ub_c * a)
     variables = list(model.variables) + [slack_prefix + str(i) for i in range(ns)]
     out = QuboModel(variables, np.diag(Qs).copy(), np.zeros(N + 1, dtype=np.int32),
                     np.zeros(0, dtype=np.int32), np.zeros(0), c_pair=0.0,
-                    offset=model.offset + lam * lb_c * lb_c,
+                    offset=model.offset + lam * ub_c * ub_c,
                     info=dict(model.info, slack=ns, lb=lb_c, ub=ub_c))
     out._dense = Qs
     return out

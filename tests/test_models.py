@@ -160,7 +160,7 @@ def test_size_window_penalty_matches_bqm_lookalike():
     bqm = BinaryQuadraticModel.from_qubo(Q)
     slack = bqm.add_linear_inequality_constraint([(v, 1) for v in bqm.variables], lb=3, ub=30 / 6,
                                                  lagrange_multiplier=0.7, label="c1_constraint")
-    assert [c for _, c in slack] == [-1, -1]                  # span 5 - 3 = 2 -> coefficients 1, 1
+    assert [c for _, c in slack] == [1, 1]                    # int(5 - 3) = 2 -> floor(log2 2) = 1 bit + remainder 1
     base = models.qubo_dict_to_model(Q)
     pen = models.add_size_window_penalty(base, lb=3, ub=30 / 6, lagrange_multiplier=0.7)
     assert pen.num_variables == base.num_variables + 2
@@ -169,12 +169,44 @@ def test_size_window_penalty_matches_bqm_lookalike():
         z = rng.randint(0, 2, size=pen.num_variables)
         sample = dict(zip(pen.variables, z.tolist()))
         assert pen.energies(z[None, :])[0] == pytest.approx(bqm.energy(sample), rel=1e-10, abs=1e-9)
-    # feasible point (4 ones, slack = 1): zero penalty
+    # feasible point: 4 ones + one slack bit = 5 = ub: zero penalty
     z = np.zeros(pen.num_variables, dtype=int)
     z[:4] = 1
     z[base.num_variables] = 1
-    cut_only = base.energies(z[None, :base.num_variables])[0]
-    assert pen.energies(z[None, :])[0] == pytest.approx(cut_only, abs=1e-9)
+    assert pen.energies(z[None, :])[0] == pytest.approx(base.energies(z[None, :base.num_variables])[0], abs=1e-9)
+
+
+def test_size_window_known_answers_n256_lb40():
+    """dimod's construction with the reference's own arguments (BQM_clustering.py:376-380: lb = size_limit, ub = n / 6,
+    FRACTIONAL): n = 256, lb = 40 -> ub_c = 42.666..., slack bound int(2.666) = 2 -> coefficients [1, 1]; the penalty
+    lagrange * (s + t0 + t1 - 128/3)^2 has its minimum lagrange / 9 at sizes 41..43 (never zero), 4/9 lagrange at 40
+    and 44.  Hand-computed; dimod itself is not importable here (parity unpinned)."""
+    from scrna_seq_qannealing_clustering_amd.bqm import inequality_slack
+    coeffs, ub_c = inequality_slack([1] * 256, 40, 256 / 6)
+    assert coeffs == [1, 1] and ub_c == 256 / 6
+    lam = 0.3
+    base = models.QuboModel(list(range(256)), np.zeros(256), np.zeros(257, dtype=np.int32), np.zeros(0, dtype=np.int32),
+                            np.zeros(0))
+    pen = models.add_size_window_penalty(base, lb=40, ub=256 / 6, lagrange_multiplier=lam)
+    assert pen.num_variables == 258
+
+    def best(size):
+        out = []
+        for t0 in (0, 1):
+            for t1 in (0, 1):
+                z = np.zeros(258, dtype=int)
+                z[:size] = 1
+                z[256], z[257] = t0, t1
+                out.append(pen.energies(z[None, :])[0])
+        return min(out)
+    for size, want in ((39, lam * (128 / 3 - 41) ** 2), (40, lam * 4 / 9), (41, lam / 9), (42, lam / 9), (43, lam / 9),
+                       (44, lam * 16 / 9), (45, lam * (45 - 128 / 3) ** 2)):
+        assert best(size) == pytest.approx(want, rel=1e-9)
+    # infeasible window raises, an always-feasible one adds nothing (dimod's behaviour)
+    with pytest.raises(ValueError):
+        models.add_size_window_penalty(base, lb=50, ub=256 / 6, lagrange_multiplier=lam)
+    assert models.add_size_window_penalty(base, lb=-5, ub=300, lagrange_multiplier=lam).num_variables == 256
+
 
 
 def test_synthetic_snn_shape():
