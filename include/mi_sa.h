@@ -177,6 +177,21 @@ int mi_sa_fetch(mi_sa_problem *p, void *out_states, double *out_energy, uint64_t
 int mi_sa_best(mi_sa_problem *p, int *out_index, double *out_energy, uint64_t *out_key,
                void *out_state);
 
+/* ---- several GPUs from one process (mi_multi_gpu_*) ------------------------------------
+ * problems[d] = the SAME model created on device d (mi_sa_problem_create_*(…, device = d, …)).  The R_total replicas
+ * with global ids replica_offset .. are sharded contiguously (remainders to the low devices), every device anneals
+ * its shard on its own stream -- concurrently -- and because a replica's random stream is keyed by its GLOBAL id the
+ * result does not depend on ndev.  _best: minimum over the devices of the packed (float(E), global id) key -- the
+ * reduction the one-process-per-GPU path does with one RCCL MIN all-reduce (distributed.global_best); out_state
+ * receives the winner's n states from its owner.  _fetch: states / energies of all replicas in global order, stats
+ * summed. */
+int mi_multi_gpu_anneal(mi_sa_problem *const *problems, int ndev, int R_total, uint32_t replica_offset,
+                        int num_sweeps, const double *betas, uint64_t seed, int resync_interval);
+int mi_multi_gpu_best(mi_sa_problem *const *problems, int ndev, int *out_owner, uint32_t *out_global_id,
+                      double *out_energy, void *out_state);
+int mi_multi_gpu_fetch(mi_sa_problem *const *problems, int ndev, void *out_states, double *out_energy,
+                       uint64_t *out_stats);
+
 /* ---- one-shot conveniences (host in, host out) ---------------------------------------------- */
 
 int mi_sa_qubo_dense_f32(const float *Qs, int n, double offset, int R, int num_sweeps,

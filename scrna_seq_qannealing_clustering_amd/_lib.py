@@ -60,6 +60,9 @@ def _declare(lib):
         "mi_sa_last_kernel_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "mi_sa_fetch": (C.c_int, [vp, vp, f64p, u64p]),
         "mi_sa_best": (C.c_int, [vp, ip, f64p, u64p, vp]),
+        "mi_multi_gpu_anneal": (C.c_int, [pp, C.c_int, C.c_int, C.c_uint32, C.c_int, f64p, C.c_uint64, C.c_int]),
+        "mi_multi_gpu_best": (C.c_int, [pp, C.c_int, ip, C.POINTER(C.c_uint32), f64p, vp]),
+        "mi_multi_gpu_fetch": (C.c_int, [pp, C.c_int, vp, f64p, u64p]),
         "mi_sa_qubo_dense_f32": (C.c_int, [f32p, C.c_int, C.c_double, C.c_int, C.c_int, f64p,
                                            C.c_uint64, u8p, u8p, f64p, u64p, C.c_int]),
         "mi_energy_dense_f32": (C.c_int, [f32p, C.c_int, u8p, C.c_int, C.c_double, f64p, C.c_int]),
@@ -91,7 +94,7 @@ EXPORTS = (
     "mi_sa_problem_create_dense_f32", "mi_sa_problem_create_csr_rank1_f32",
     "mi_sa_problem_create_potts_csr_f32", "mi_sa_problem_destroy", "mi_sa_problem_info",
     "mi_sa_set_option", "mi_sa_plan_slot_order", "mi_sa_problem_set_energy_model_f64", "mi_sa_debug_pace", "mi_sa_debug_stats", "mi_sa_anneal", "mi_sa_anneal_ex", "mi_sa_tempering_begin", "mi_sa_tempering_exchange", "mi_sa_tempering_state", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_last_launch_count", "mi_sa_last_kernel_name", "mi_sa_fetch", "mi_sa_best",
-    "mi_sa_qubo_dense_f32", "mi_energy_dense_f32", "mi_energy_dense_f64", "mi_energy_dense_f32_ex",
+    "mi_multi_gpu_anneal", "mi_multi_gpu_best", "mi_multi_gpu_fetch", "mi_sa_qubo_dense_f32", "mi_energy_dense_f32", "mi_energy_dense_f64", "mi_energy_dense_f32_ex",
     "mi_snn_build_f32", "mi_snn_build_ex_f32", "mi_snn_fetch_codes", "mi_snn_info", "mi_snn_fetch", "mi_snn_kernel_ms", "mi_snn_destroy",
     "mi_jaccard_cluster_stats",
 )

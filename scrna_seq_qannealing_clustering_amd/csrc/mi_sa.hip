@@ -972,6 +972,90 @@ int mi_sa_best(mi_sa_problem *p, int *out_index, double *out_energy, uint64_t *o
     return MI_OK;
 }
 
+// ---- several GPUs from ONE process (callers without a process-per-GPU launcher) -------------------------------
+// Replicas are independent chains: problem d (the same model created on device d) runs the contiguous shard d of the
+// global replica ids; the anneals are asynchronous on each device's own stream, so the devices run concurrently; the
+// best replica is the minimum of the per-device packed keys -- the same reduction distributed.global_best does with one
+// RCCL all-reduce when there is one process per GPU.
+static void shard_of(int R_total, int d, int ndev, int *lo, int *hi)
+{
+    const int base = R_total / ndev, rem = R_total % ndev;
+    *lo = d * base + (d < rem ? d : rem);
+    *hi = *lo + base + (d < rem ? 1 : 0);
+}
+
+static int multi_check(mi_sa_problem *const *problems, int ndev)
+{
+    if (!problems || ndev < 1) return fail(MI_EINVAL, "need ndev >= 1 problem handles");
+    for (int d = 0; d < ndev; ++d) {
+        if (!problems[d]) return fail(MI_EINVAL, "problem %d is NULL", d);
+        if (problems[d]->kind != problems[0]->kind || problems[d]->n != problems[0]->n || problems[d]->K != problems[0]->K)
+            return fail(MI_EINVAL, "problem %d is not the model of problem 0 (kind / size differ)", d);
+    }
+    return MI_OK;
+}
+
+int mi_multi_gpu_anneal(mi_sa_problem *const *problems, int ndev, int R_total, uint32_t replica_offset,
+                        int num_sweeps, const double *betas, uint64_t seed, int resync_interval)
+{
+    int rc = multi_check(problems, ndev);
+    if (rc) return rc;
+    if (R_total < ndev) return fail(MI_EINVAL, "R_total = %d replicas cannot be sharded over %d devices", R_total, ndev);
+    for (int d = 0; d < ndev; ++d) {
+        int lo, hi;
+        shard_of(R_total, d, ndev, &lo, &hi);
+        rc = mi_sa_anneal_ex(problems[d], hi - lo, replica_offset + (uint32_t)lo, num_sweeps, betas, seed, nullptr,
+                             resync_interval, 0u, 0u);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
+int mi_multi_gpu_best(mi_sa_problem *const *problems, int ndev, int *out_owner, uint32_t *out_global_id,
+                      double *out_energy, void *out_state)
+{
+    int rc = multi_check(problems, ndev);
+    if (rc) return rc;
+    int owner = -1, best_idx = 0;
+    uint64_t best_key = ~0ull;
+    for (int d = 0; d < ndev; ++d) {
+        int idx = 0;
+        uint64_t key = 0;
+        rc = mi_sa_best(problems[d], &idx, nullptr, &key, nullptr);
+        if (rc) return rc;
+        if (owner < 0 || key < best_key) { owner = d; best_key = key; best_idx = idx; }
+    }
+    mi_sa_problem *p = problems[owner];
+    HIP_TRY(hipSetDevice(p->device));
+    if (out_owner) *out_owner = owner;
+    if (out_global_id) *out_global_id = (uint32_t)(best_key & 0xffffffffull);
+    if (out_energy) HIP_TRY(hipMemcpy(out_energy, p->d_energy + best_idx, sizeof(double), hipMemcpyDeviceToHost));
+    if (out_state)
+        HIP_TRY(hipMemcpy(out_state, (const char *)p->d_states + (size_t)best_idx * p->n * p->state_elem,
+                          (size_t)p->n * p->state_elem, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_multi_gpu_fetch(mi_sa_problem *const *problems, int ndev, void *out_states, double *out_energy, uint64_t *out_stats)
+{
+    int rc = multi_check(problems, ndev);
+    if (rc) return rc;
+    size_t done = 0;
+    uint64_t tot[3] = {0, 0, 0};
+    for (int d = 0; d < ndev; ++d) {
+        mi_sa_problem *p = problems[d];
+        if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on problem %d", d);
+        uint64_t st[3] = {0, 0, 0};
+        rc = mi_sa_fetch(p, out_states ? (char *)out_states + done * p->n * p->state_elem : nullptr,
+                         out_energy ? out_energy + done : nullptr, st);
+        if (rc) return rc;
+        for (int k = 0; k < 3; ++k) tot[k] += st[k];
+        done += (size_t)p->last_R;
+    }
+    if (out_stats) { out_stats[0] = tot[0]; out_stats[1] = tot[1]; out_stats[2] = tot[2]; }
+    return MI_OK;
+}
+
 int mi_sa_qubo_dense_f32(const float *Qs, int n, double offset, int R, int num_sweeps,
                          const double *betas, uint64_t seed, const uint8_t *init,
                          uint8_t *out_states, double *out_energy, uint64_t *out_stats, int device)

@@ -186,6 +186,31 @@ def plot_and_save_graph_out_cqm_2(G, pos, dirs, sampleset_cqm, num_of_clusters):
     _write(G, dirs["graph_out_cqm"])
 
 
+def plot_and_save_graph_out_cqm_multi(G, pos, dirs, sampleset_cqm, num_of_clusters, number_of_samples,
+                                      out_dir: str = "./graphs_multi_samples"):
+    """`plot_and_save.py:104-126`: one labelled graph per sample for the first ``number_of_samples - 1`` samples of the
+    set (the reference slices ``samples()[:number_of_samples-1]``), written as ``<out_dir>/sample_number<i>.gexf``
+    (+ ``.png`` when a layout is given) with the cluster in node attribute ``label1``.  Returns the written paths."""
+    samples = list(sampleset_cqm.samples()[:max(int(number_of_samples) - 1, 0)])
+    paths = []
+    for i, sample in enumerate(samples):
+        graph_name = os.path.join(out_dir, "sample_number" + str(i))
+        labels = defaultdict(int)
+        for node in G.nodes:
+            p = sample[node] if node in sample else _cluster_of(sample, int(node), num_of_clusters)
+            if p is not None:
+                labels[node] = int(p)
+        plt = _canvas(pos)
+        if plt is not None:
+            nx.draw(G, pos=pos, with_labels=False, node_color=[labels.get(v, -1) for v in G.nodes], node_size=10,
+                    cmap=plt.cm.rainbow)
+            _save(plt, graph_name + ".png")
+        nx.set_node_attributes(G, dict(labels), name="label1")
+        _write(G, graph_name + ".gexf")
+        paths.append(graph_name + ".gexf")
+    return paths
+
+
 def plot_and_save_graph_out_mvc(G, pos, dirs):
     """`plot_and_save.py:85-102`: the sub-sampling result (``label1`` = 1 kept).  Returns the edges that touch a
     kept node and the rest."""

@@ -162,3 +162,43 @@ def test_sample_dqm_on_a_graph_with_rows_wider_than_64():
     ss = MI355XSampler().sample_dqm(build_dqm_potts(G, 2, 0.005), num_reads=32, num_sweeps=300, seed=3)
     lab = np.array([ss.first.sample[str(i)] for i in range(240)])
     assert len(set(lab[:120])) == 1 and len(set(lab[120:])) == 1 and lab[0] != lab[239]
+
+
+def test_multi_gpu_c_entries_shard_invariance():
+    """mi_multi_gpu_anneal / _best / _fetch through ctypes: the same model on `ndev` handles (here three
+    handles on device 0 standing in for three GPUs -- the box has one), 11 replicas sharded 4 + 4 + 3: states, energies
+    and the winner equal one handle running all 11, i.e. the oracle on global ids 5..15."""
+    import ctypes as C
+    from oracle import sa_oracle as so
+    from scrna_seq_qannealing_clustering_amd import _lib
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    fx = load_fixture("aniso")
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    args = (m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32), float(np.float32(m.c_pair)))
+    betas = np.ascontiguousarray(np.geomspace(0.01, 8.0, 25))
+    lib = _lib.load()
+    probs = [Problem.csr_rank1(*args) for _ in range(3)]
+    try:
+        handles = (C.c_void_p * 3)(*[p._h for p in probs])
+        hp = C.cast(handles, C.POINTER(C.c_void_p))
+        _lib.check(lib.mi_multi_gpu_anneal(hp, 3, 11, C.c_uint32(5), len(betas), betas.ctypes.data_as(C.POINTER(C.c_double)),
+                                           C.c_uint64(21), 0))
+        st = np.empty((11, 256), dtype=np.uint8)
+        en = np.empty(11, dtype=np.float64)
+        stats = np.zeros(3, dtype=np.uint64)
+        _lib.check(lib.mi_multi_gpu_fetch(hp, 3, st.ctypes.data_as(C.c_void_p), en.ctypes.data_as(C.POINTER(C.c_double)),
+                                          stats.ctypes.data_as(C.POINTER(C.c_uint64))))
+        owner, gid, e = C.c_int(-1), C.c_uint32(0), C.c_double(0.0)
+        best = np.empty(256, dtype=np.uint8)
+        _lib.check(lib.mi_multi_gpu_best(hp, 3, C.byref(owner), C.byref(gid), C.byref(e), best.ctypes.data_as(C.c_void_p)))
+        with pytest.raises(_lib.MiSaError):
+            _lib.check(lib.mi_multi_gpu_anneal(hp, 3, 2, C.c_uint32(0), len(betas), betas.ctypes.data_as(C.POINTER(C.c_double)),
+                                               C.c_uint64(21), 0))
+    finally:
+        for p in probs:
+            p.close()
+    ost, oen, ostats = so.sa_csr_rank1_philox(*args, 11, betas, 21, replica_offset=5)
+    assert np.array_equal(st, ost) and np.allclose(en, oen, rtol=1e-9, atol=1e-9) and int(stats[1]) == int(ostats[1])
+    k = int(np.argmin(oen.astype(np.float32)))                 # the cross-device key compares float(E), ties by id
+    assert gid.value == 5 + k and owner.value == (0 if k < 4 else (1 if k < 8 else 2))
+    assert e.value == en[k] and np.array_equal(best, st[k])

@@ -93,6 +93,19 @@ def test_dqm_and_cqm_outputs_write_label1(tmp_path):
     assert [a.nodes[v]["label1"] for v in "0123"] == [b.nodes[v]["label1"] for v in "0123"] == [2, 2, 0, 1]
 
 
+def test_cqm_multi_writes_one_graph_per_sample(tmp_path):
+    """plot_and_save.py:104-126: the first number_of_samples - 1 samples, one labelled GEXF each."""
+    import numpy as np
+    G = _toy()
+    ss = SampleSet(np.asarray([[2, 2, 0, 1], [0, 1, 1, 2], [1, 1, 1, 0]]), np.asarray([-3.0, -2.0, -1.0]), list("0123"),
+                   vartype="DISCRETE")
+    paths = outputs.plot_and_save_graph_out_cqm_multi(G, None, {}, ss, 3, 3, out_dir=str(tmp_path / "multi"))
+    assert [p.split("/")[-1] for p in paths] == ["sample_number0.gexf", "sample_number1.gexf"]
+    a, b = nx.read_gexf(paths[0]), nx.read_gexf(paths[1])
+    assert [a.nodes[v]["label1"] for v in "0123"] == [2, 2, 0, 1]            # samples come sorted by energy
+    assert [b.nodes[v]["label1"] for v in "0123"] == [0, 1, 1, 2]
+
+
 def test_cqm_2_addresses_nodes_by_subindex(tmp_path):
     G = _toy()
     for sub, v in enumerate(["3", "2", "1", "0"]):
