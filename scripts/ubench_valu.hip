@@ -153,7 +153,7 @@ static int run(const char *name, K kern, int waves_per_simd, int inst_per_iter, 
 
 int main()
 {
-    for (int W : {1, 4, 8}) {
+    for (int W : {1, 2, 3, 4, 8}) {
         const size_t lds = 160 * 1024 / (4 * W) - 64;     // forces exactly W waves per SIMD... at most
         run("v_xor_b32", k_xor, W, 16, lds, 12345u);
         run("v_add_u32", k_add_u32, W, 16, lds, 12345u);
@@ -178,7 +178,7 @@ int main()
         run("v_log_f32", k_log, W, 16, lds, 12345u);
         run("v_rcp_f32", k_rcp, W, 16, lds, 12345u);
         for (int random : {0, 1}) {
-            if (W == 8) break;                            // 5 KB of LDS per wave: the gather spans do not fit
+            if (W == 8 || W == 2 || W == 3) break;        // (8: 5 KB of LDS per wave: the gather spans do not fit)
             char nm[64];
             snprintf(nm, sizeof nm, "ds_read_u8  %s 2688 B", random ? "random" : "linear");
             run(nm, k_lds_gather<1>, W, 16, lds, 777u, 2688, random);

@@ -628,6 +628,11 @@ def test_structured_kernels_random_models(seed):
         p.anneal(R, betas, 7 + seed, replica_offset=off)
         st, en, info = p.fetch()
         perm = p.perm
+        # the two-replicas-per-wavefront kernel wherever the model is eligible for it (else this is K2 again)
+        p.set_option("k2_pair", 1)
+        p.anneal(R, betas, 7 + seed, replica_offset=off)
+        st_p, en_p, info_p = p.fetch()
+        assert np.array_equal(st_p, st) and np.array_equal(en_p, en) and info_p["accepted"] == info["accepted"]
     if perm is None:
         o_args, back = (rowptr, col, val, lin, c_pair), slice(None)
     else:

@@ -173,6 +173,26 @@ def test_gpu_continuation_and_per_replica_beta_parity(kind):
 
 
 @pytest.mark.gpu
+def test_gpu_per_replica_beta_across_launch_chunks_of_the_wave_kernel():
+    """K1 (variant 1) serves more replicas than are resident at once in chunks; with one temperature PER REPLICA every
+    chunk has to read its own slice of the temperatures (round 1 read the first chunk's for all of them)."""
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    rs = np.random.RandomState(12)
+    n, R = 40, 40000
+    A = rs.normal(size=(n, n)).astype(np.float32)
+    Qs = np.ascontiguousarray((A + A.T) / 2)
+    per = np.geomspace(0.02, 8.0, R)
+    with Problem.dense(Qs) as p:
+        p.set_option("variant", 1)
+        p.anneal(R, per, 9, num_sweeps=3)
+        st, en, info = p.fetch()
+        assert p.kernel_name().startswith("k_anneal_dense<") and p.launch_count() >= 2
+    ost, oen, ostats = so.sa_dense_philox(Qs, R, per, 9, num_sweeps=3)
+    assert np.array_equal(st, ost) and info["accepted"] == int(ostats[1])
+    assert np.allclose(en, oen, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
 def test_gpu_parallel_tempering_matches_oracle_engine_and_improves_on_sa():
     """BASELINE config 5 in miniature: DQM K=3 on the reference's blobs graph, 8 rungs x 8 chains."""
     from scrna_seq_qannealing_clustering_amd.engine import Problem
