@@ -311,6 +311,69 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
     return 0;
 }
 
+/* How often does fp32 chain arithmetic decide differently from fp64 (neal computes in doubles)?  Runs chain (2b) exactly
+ * as above (the fp32 decisions drive the trajectory) and, for every proposal, also evaluates the same predicate in
+ * fp64 from the same state and the same random word:  g64 = lin + sum S_ij x_j,  f64 = g64 + c (s - x_i),
+ * accept64 iff +-f64 < -ln(u) / beta  with the natural logarithm of libm.  counts[0] += proposals,
+ * counts[1] += proposals on which the two predicates disagree, counts[2] += accepted (fp32). */
+int orc_csr_rank1_fp32_vs_fp64_decisions(const int *rowptr, const int *col, const float *val, const float *lin,
+                                         float c_pair, int n, int R, uint32_t replica_offset, int num_sweeps,
+                                         const double *betas, uint64_t seed, uint64_t *counts)
+{
+    uint64_t prop = 0, differ = 0, acc = 0;
+#pragma omp parallel for schedule(dynamic) reduction(+ : prop, differ, acc)
+    for (int r = 0; r < R; ++r) {
+        const uint32_t gid = replica_offset + (uint32_t)r;
+        uint8_t *x = (uint8_t *)malloc((size_t)n);
+        float g[ORC_SLOT];
+        double g64[ORC_SLOT];
+        int S = 0;
+        for (int i = 0; i < n; ++i) { x[i] = (uint8_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) >> 31); S += x[i]; }
+        for (int s = 0; s < num_sweeps; ++s) {
+            const float T = (float)(1.0 / betas[s]);
+            for (int i0 = 0; i0 < n; i0 += ORC_SLOT) {
+                const int i1 = i0 + ORC_SLOT < n ? i0 + ORC_SLOT : n;
+                for (int i = i0; i < i1; ++i) {
+                    float gi = lin[i];
+                    double gd = (double)lin[i];
+                    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+                        if (x[col[e]]) { gi = gi + val[e]; gd += (double)val[e]; }
+                    g[i - i0] = gi;
+                    g64[i - i0] = gd;
+                }
+                for (int i = i0; i < i1; ++i) {
+                    const uint32_t w = chain_word(seed, (uint32_t)i, (uint32_t)s, gid, 0);
+                    const float thr = orc_neglog_u(w) * T;
+                    const float fi = g[i - i0] + c_pair * (float)(S - (int)x[i]);
+                    const float dE = x[i] ? -fi : fi;
+                    const int a32 = dE < thr;
+                    union { uint32_t u; float f; } cv;
+                    cv.u = 0x3f800000u | (w >> 9);
+                    const double u = 2.0 - (double)cv.f;
+                    const double f64 = g64[i - i0] + (double)c_pair * (double)(S - (int)x[i]);
+                    const int a64 = (x[i] ? -f64 : f64) < -log(u) / betas[s];
+                    ++prop;
+                    differ += (uint64_t)(a32 != a64);
+                    if (a32) {
+                        const float sgn = x[i] ? -1.0f : 1.0f;
+                        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+                            if (col[e] >= i0 && col[e] < i1) {
+                                g[col[e] - i0] = g[col[e] - i0] + sgn * val[e];
+                                g64[col[e] - i0] += (double)sgn * (double)val[e];
+                            }
+                        S += x[i] ? -1 : 1;
+                        x[i] ^= 1;
+                        ++acc;
+                    }
+                }
+            }
+        }
+        free(x);
+    }
+    counts[0] += prop; counts[1] += differ; counts[2] += acc;
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* (2c) Potts / DQM chain on CSR + uniform pair term -- mirror of kernel K3                     */
 /* ------------------------------------------------------------------------------------------ */

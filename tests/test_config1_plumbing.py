@@ -64,3 +64,28 @@ def test_p3_neal_restatement_and_philox_chain_reach_the_same_optimum(config1):
     S0 = [n for n in nodes if not lut[n]]
     S1 = [n for n in nodes if lut[n]]
     assert len(S0) + len(S1) == 512 and min(len(S0), len(S1)) > 5
+
+
+def test_fp32_chain_decisions_differ_from_fp64_on_about_one_proposal_in_a_million():
+    """The device chains compute in fp32 where neal computes in doubles (SURVEY.md 8d allows fp32 Q).  On bench.py's
+    model the two predicates -- same state, same random word -- disagree on fewer than 5 proposals per million over a
+    whole 200-sweep schedule (the fp32 field carries ~1e-7 relative rounding, the threshold polynomial 1e-7): energies
+    are re-evaluated in fp64 anyway, so what fp32 costs is a slightly different, equally valid, random trajectory."""
+    import ctypes as C
+    import bench
+    from oracle import sa_oracle as so
+    m, Qs, betas, _, _ = bench.build_workload()
+    betas = np.ascontiguousarray(betas[::5])
+    rowptr = np.ascontiguousarray(m.rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(m.col, dtype=np.int32)
+    val = np.ascontiguousarray(m.val, dtype=np.float32)
+    lin = np.ascontiguousarray(m.lin, dtype=np.float32)
+    counts = np.zeros(3, dtype=np.uint64)
+    i32p, f32p = C.POINTER(C.c_int), C.POINTER(C.c_float)
+    rc = so.lib().orc_csr_rank1_fp32_vs_fp64_decisions(
+        rowptr.ctypes.data_as(i32p), col.ctypes.data_as(i32p), val.ctypes.data_as(f32p), lin.ctypes.data_as(f32p),
+        C.c_float(float(np.float32(m.c_pair))), C.c_int(m.num_variables), C.c_int(16), C.c_uint32(0), C.c_int(len(betas)),
+        betas.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(1234), counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == 0 and int(counts[0]) == 16 * len(betas) * m.num_variables
+    assert 0.2 < int(counts[2]) / int(counts[0]) < 0.5
+    assert int(counts[1]) / int(counts[0]) < 5e-6
