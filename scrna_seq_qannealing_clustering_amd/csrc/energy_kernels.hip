@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(256) k_fill_f64(double *__restrict__ out, int 
 // Operand maps of v_mfma_f32_32x32x2_f32:  A: lane l holds A[i = l & 31][k = l >> 5];  B: lane l holds
 // B[k = l >> 5][j = l & 31];  C/D: register q of lane l is C[row = (q & 3) + 8 (q >> 2) + 4 (l >> 5)][col = l & 31].
 constexpr int kGemmTile = 128, kGemmKC = 32;
+constexpr int kFoldChunks = 4;        // fp32 partial sums run over kFoldChunks * kGemmKC = 128 terms before they are folded into fp64
 
 __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restrict__ Qs, int n,
                                                            const uint8_t *__restrict__ Xt, int R, int Rpad,
@@ -171,9 +172,12 @@ __global__ void __launch_bounds__(256) k_energy_dense_mfma(const float *__restri
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (c + 1 < chunks) store_chunk(b ^ 1);                  // (buffer b^1 was last read before the previous barrier)
-        // fold the <= 32-term fp32 partial sums under the state mask: the 16 masked values a lane holds per
-        // accumulator are first added in fp32 by a fixed balanced tree (4 more roundings on top of a 32-term
-        // chain), then ONE fp64 add per accumulator -- fp64 instructions are the expensive ones here
+        // every kFoldChunks chunks (and at the end) fold the <= 128-term fp32 partial sums under the state mask: the
+        // 16 masked values a lane holds per accumulator are first added in fp32 by a fixed balanced tree (4 more
+        // roundings on top of the chain), then ONE fp64 add per accumulator -- fp64 instructions are the expensive
+        // ones here, and the fold (mask, tree, clearing 64 accumulator registers) is vector work the matrix pipe
+        // waits for: folding after every 32-term chunk held the kernel at 0.48 of the f32 MFMA peak
+        if (((c - c_begin) % kFoldChunks) == kFoldChunks - 1 || c + 1 == chunks)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float m0[16], m1[16];
