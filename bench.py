@@ -247,9 +247,9 @@ def dense_xl_50k(rank_device, n=50000, replicas=128, sweeps=8):
     """BASELINE config 4 in its literal form -- the one kernel of the path that really streams Q from HBM: a
     synthetic 50 000-cell SNN graph built on the GPU (snn.build_snn), the clustering_bqm QUBO as a dense fp32
     matrix (10.6 GB resident in HBM), K1x (one workgroup per replica; an ACCEPTED flip streams one padded row of
-    Q), the first `sweeps` sweeps of the 1000-step schedule.  `hbm_roofline`: the 4 n-byte row model against the
-    8 TB/s spec peak; `fabric` = what rocprofv3 FETCH_SIZE x 2 saw on this shape (profiles/r02_dense50k.json) --
-    replicas walk the rows in the same order, so the Infinity Cache serves part of the row reads."""
+    Q), the first `sweeps` sweeps of the 1000-step schedule.  `hbm_roofline` = what rocprofv3 FETCH_SIZE x 2 saw on
+    this shape (profiles/r02_dense50k.json) against the 8 TB/s spec peak; `row_model` = the 4 n-byte row model -- the
+    replicas walk the rows in the same order, so the Infinity Cache serves most of those reads."""
     from scrna_seq_qannealing_clustering_amd import models, snn
     from scrna_seq_qannealing_clustering_amd.engine import Problem
     rng = np.random.RandomState(1)
@@ -276,18 +276,21 @@ def dense_xl_50k(rank_device, n=50000, replicas=128, sweeps=8):
     rows_streamed = info["accepted"] + replicas * n // 2          # + field initialisation: ~n/2 rows per replica
     row_gbps = rows_streamed * 4.0 * n_pad / (ms * 1e-3) / 1e9
     rec = _profile_json("r02_dense50k.json")
-    fabric = None
+    hbm = None
     if rec and rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("n") == n:
-        fabric = {"GBps": rec["fabric_read_GBps"], "frac_of_hbm_peak": rec["fabric_read_GBps"] / HBM_PEAK_GBPS,
-                  "source": "profiles/r02_dense50k.json (rocprofv3 --pmc FETCH_SIZE x 2, same shape)"}
+        hbm = {"bound": "hbm", "achieved": rec["fabric_read_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "frac": rec["fabric_read_GBps"] / HBM_PEAK_GBPS,
+               "source": "profiles/r02_dense50k.json: rocprofv3 --pmc FETCH_SIZE x 2 on this shape (scripts/pmc_dense50k.sh)"}
     return {"kernel": kname, "n": n, "replicas": replicas, "sweeps": sweeps, "kernel_ms": ms,
             "updates_per_s": replicas * sweeps * n / (ms * 1e-3), "acceptance": info["accepted"] / info["proposals"],
             "dense_Q_bytes": 4 * n * n_pad, "graph_edges": int(len(m.col) // 2),
-            "hbm_roofline": {"bound": "hbm", "achieved": row_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": row_gbps / HBM_PEAK_GBPS,
-                             "model": "4 * n_pad bytes of Q per ACCEPTED flip (SURVEY.md 8d: 4n per proposal; a rejected "
-                                      "proposal needs no row with cached fields)"},
-            "fabric": fabric, "host_build_s": t_build, "upload_s": t_upload, "best_energy": float(en.min())}
+            "hbm_roofline": hbm,
+            "row_model": {"GBps": row_gbps, "bytes_per_accepted_flip": 4 * n_pad,
+                          "note": "4 * n_pad bytes of Q per ACCEPTED flip (SURVEY.md 8d: 4n per proposal; a rejected proposal needs "
+                                  "no row with cached fields) / kernel time: what the workgroups request.  The replicas walk the "
+                                  "rows in step at the hot end of the schedule, so L2 / Infinity Cache serve most of it: the HBM "
+                                  "side sees `hbm_roofline.achieved`"},
+            "host_build_s": t_build, "upload_s": t_upload, "best_energy": float(en.min())}
 
 
 def main():
