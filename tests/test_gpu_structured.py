@@ -168,7 +168,7 @@ def test_csr_rank1_two_replicas_per_wavefront():
     (one idle seat), given initial states, a run cut in two (MI_F_CONTINUE + sweep_offset), one constant temperature
     per replica, a replica offset, the fp64 energy model; the wider (D = 32) adjacency as well."""
     from scrna_seq_qannealing_clustering_amd import graphs
-    for (n, k, ordv, ncl, seed) in ((900, 5, 15, 5, 4), (700, 8, 30, 4, 6)):
+    for (n, k, ordv, ncl, seed) in ((900, 5, 15, 5, 4), (2000, 8, 30, 6, 6)):
         nodes, eu, ev, w, _ = graphs.synthetic_snn(n, k, 15, ordv, ncl, seed=seed, spread=2.5)
         m = models.build_bqm_qubo(graphs.EdgeListGraph(nodes, eu, ev, w), 0.05)
         c_pair = float(np.float32(m.c_pair))
@@ -184,6 +184,7 @@ def test_csr_rank1_two_replicas_per_wavefront():
                 p.set_option("k2_pair", mode)
                 p.anneal(7, betas, 8, replica_offset=5)
                 a = p.fetch()
+                assert ("pair" in p.kernel_name()) == (mode == 1)          # the model is eligible: the option decides
                 p.anneal(7, betas, 8, initial_states=init)
                 b = p.fetch()
                 p.anneal(7, betas[:11], 8, initial_states=init)
