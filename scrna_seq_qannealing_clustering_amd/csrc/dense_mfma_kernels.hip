@@ -2,30 +2,51 @@
 //
 // Same chain as K1 / K1w, bit for bit; what changes is WHO holds the cached fields.
 // A workgroup = 16 wavefronts = 16 replicas, but the fields of all 16 replicas live TRANSPOSED, as the
-// accumulators of f32-input MFMAs:  wave w owns the columns [w*S, (w+1)*S) (S = 4*NT = n_pad/16) of every
-// replica, as NT/4 tiles of v_mfma_f32_16x16x4_f32 accumulators
-//       C[i][r] = f_{column w*S + 16*tile + i}(replica r)        (lane l: r = l & 15, i = 4*(l >> 4) + reg).
-// The flips a unit of 4 consecutive rows R0..R0+3 causes in the 16 replicas are ONE rank-4 update
-//       F[:, r] += sum_k Q2[R0+k][:] * s_k(r),      s_k(r) in {-1, 0, +1},
-// i.e. per tile one MFMA with A[i][k] = Q2[R0+k][column i] (read from the LDS ring, 4 B/lane) and
-// B[k][r] = s_k(r).  The f32-input MFMA is an exact fp32 fmaf chain in k order
+// accumulators of f32-input MFMAs.  The n_pad = 64*NT columns are cut into blocks of 16; block c belongs to
+// wave c % 16 as its tile c / 16 (round robin, so consecutive blocks sit on different SIMDs):
+//       acc[tile][reg] of lane l = f_{column 16*c + 4*(l >> 4) + reg}(replica l & 15).
+// The flips that 4 consecutive rows R..R+3 cause in the 16 replicas are ONE rank-4 update
+//       F[:, r] += sum_k Q2[R+k][:] * s_k(r),      s_k(r) in {-1, 0, +1},
+// i.e. per tile one v_mfma_f32_16x16x4_f32 with A[i][k] = Q2[R+k][column i] (read from the LDS ring, 4 B per
+// lane) and B[k][r] = s_k(r).  The f32-input MFMA is an exact fp32 fmaf chain in k order
 //       D = fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C))))
 // which is precisely the oracle's "f += sgn * Q2" applied for the accepted rows in row order (a rejected
-// row has s = 0 and fma(a, 0, C) = C).  So a Q row read from LDS once serves all 16 replicas: LDS traffic
-// per unit drops from (accepted flips) x 11 KB to 45 KB flat, and the kernel is bound by the fp32 FMA rate
-// (the MFMA pipe) instead of the LDS->VGPR fill rate that bounds K1w at the hot end of a schedule.
+// row has s = 0 and fma(a, 0, C) = C).  A Q row read from LDS once serves all 16 replicas: LDS traffic per
+// 4 rows is 45 KB flat instead of (accepted flips) x 11 KB, and the kernel is bound by the fp32 MFMA rate
+// (256 flop/clk/CU: 2*16*n_pad^2 flop per sweep and workgroup) instead of the LDS->VGPR fill rate that bounds
+// K1w at the hot end of a schedule.
 //
-// The accept/reject decisions of a unit are made by the 16 lanes that hold the four fields involved
-// (owner wave R0 / S, tile (R0 % S) / 16, lane quarter (R0 % 16) / 4), sequentially over the 4 rows, with
-// the intra-unit couplings applied by the same fmaf chain the MFMA will execute.  Thresholds come from the
-// same Philox addressing as everywhere else (wave w draws for replica w, 4 slots per block) through LDS.
+// Schedule (round 2).  Decisions are taken per BLOCK of 16 rows, updates applied per UNIT of 4 rows (the K of
+// one MFMA; the LDS ring holds 3 units of 4 x 11 KB):
+//   * DIAG(c): the owner wave of block c walks its 16 rows sequentially for the 16 replicas at once.  Lane
+//     4r + q holds the fields t_j of replica r for the columns j = q, 4+q, 8+q, 12+q of the block; step k
+//     decides row k in the lanes q = k % 4, broadcasts s_k inside the quad (DPP) and applies the couplings
+//     Q2[16c+k][16c+j] -- the same fmaf chain, in the same order, that the MFMAs apply to the accumulators
+//     afterwards (fields of rows already decided are dead and may take garbage).  It leaves s_k(r) as the B
+//     operands of the block's four MFMA units, the new state bits, and a 4-bit "unit has a flip" word.
+//   * look-ahead: DIAG(c+1) runs in the LAST unit of block c, on a copy of the accumulator tile taken one unit
+//     earlier plus that unit's four rows applied by hand -- so it overlaps the MFMAs of the other 15 waves
+//     and the chain never waits for a whole panel update.  One s_barrier per unit (it was two, with the
+//     decisions of 4 rows serialised between them: 2900 cycles per unit, now the 16 x 11 MFMAs = 1408).
+//   * the 16x16 coupling block of DIAG(c+1) is fetched by LDS-DMA three units ahead (wave 15, which loads no
+//     ring piece), transposed on the way ([k][q][m], one ds_read_b128 per step).
+// Thresholds come from the same Philox addressing as everywhere else (wave w draws for replica w, 4 slots =
+// 256 rows per block of random numbers), through LDS.
 //
-// Used for the hot part of a schedule only (acceptance above ~10 %): the launcher alternates K1m and K1w
-// per chunk of sweeps (mi_sa_device.h "kernel scheduling"); both leave bits + cached fields in HBM.
+// Used for the hot part of a schedule (acceptance above ~10 %): the launcher alternates K1m and K1w per
+// chunk of sweeps (mi_sa_device.h "kernel scheduling"); both leave bits + cached fields in HBM.
 #include "mi_sa_device.h"
 
 #ifndef MI_NT
 #error "compile with -DMI_NT=<4,8,...,44>"
+#endif
+
+// diagnostic timing builds (-DMI_K1M_DEBUG; results are wrong): DenseArgs::debug bit0 = no ring DMA, bit2 = no
+// decision chain, bit3 = no MFMAs.  -DMI_K1M_TICKS: s_memtime phase counters in stats[4..12].
+#ifdef MI_K1M_DEBUG
+#define K1M_DBG(bit) ((a.debug & (bit)) != 0)
+#else
+#define K1M_DBG(bit) false
 #endif
 
 namespace mi_sa_impl {
@@ -38,24 +59,46 @@ template <int NT>
 struct MfCfg {
     static constexpr int M = NT / 4;                 // 16x16 tiles per wave
     static constexpr int NPAD = NT * 64;             // padded number of variables
-    static constexpr int S = NPAD / 16;              // columns per wave (= 16 * M)
+    static constexpr int NB = NPAD / 16;             // 16-row blocks (= 16 * M)
     static constexpr int ROWS = (NPAD + 16) * 4;     // LDS row stride: +64 B makes the A reads conflict-free
     static constexpr int UNITB = 4 * ROWS;           // a unit = 4 rows = the K of one MFMA
     static constexpr int U = 3;
-    static constexpr int G = NT / 4;                 // 1 KiB pieces per row
+    static constexpr int G = NT / 4;                 // 1 KiB pieces per row = waves that load the ring
     static constexpr int RING = U * UNITB;
-    static constexpr int THR = RING;                 // float thr[4][64][16]
-    static constexpr int XB = THR + 4 * 64 * 16 * 4; // uint16 xbits[NPAD]  (bit r = x of replica r)
-    static constexpr int SB = XB + NPAD * 2;         // float S[2][4][16]
-    static constexpr int FL = SB + 2 * 4 * 16 * 4;   // uint32 flag[2], wg_flips
-    static constexpr int TOTAL = FL + 64;
-    static constexpr bool ok = TOTAL <= 160 * 1024;
+    static constexpr int THRS = 260;                 // floats per replica: 256 rows + 4 (conflict-free reads)
+    static constexpr int THR = RING;                 // float thr[16][THRS]
+    static constexpr int XR = THR + 16 * THRS * 4;   // uint16 xr[NB][16]: bit k = x of row 16*block + k
+    static constexpr int SB = XR + NB * 16 * 2;      // float S[2][4][64]: B operands of a block's 4 units
+    static constexpr int CB = SB + 2 * 256 * 4;      // float C[16][4][4]: coupling block, [k][q][m]
+    static constexpr int TB = CB + 256 * 4;          // float T[16][20]: accumulator tile on its way to DIAG
+    static constexpr int FL = TB + 16 * 20 * 4;      // uint32 flag[2] (units with a flip), wg_flips
+    static constexpr int TOTAL = FL + 16;
+    static constexpr bool ok = TOTAL <= 160 * 1024 && G <= 15;
 };
 
 __device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char *lds_dst, int voff, int soff)
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 16,
                                              voff, soff, 0, 0);
+}
+
+// 64 lanes x 4 B, each lane from its own offset (a gather), to lds_dst + lane*4
+__device__ __forceinline__ void lds_dma_4(__amdgpu_buffer_rsrc_t rsrc, char *lds_dst, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 4,
+                                             voff, soff, 0, 0);
+}
+
+template <int QK>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), QK * 0x55, 0xf, 0xf, false));
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned int quad_perm(unsigned int v)
+{
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
 template <int NT>
@@ -65,9 +108,11 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
     __shared__ __attribute__((aligned(16))) char lds[C::TOTAL];
     if (!sched_my_turn(a)) return;
 
-    float *thrbuf = reinterpret_cast<float *>(lds + C::THR);
-    unsigned short *xbits = reinterpret_cast<unsigned short *>(lds + C::XB);
+    float *thr = reinterpret_cast<float *>(lds + C::THR);
+    unsigned short *xr = reinterpret_cast<unsigned short *>(lds + C::XR);
     float *Sbuf = reinterpret_cast<float *>(lds + C::SB);
+    float *Cbuf = reinterpret_cast<float *>(lds + C::CB);
+    float *Tbuf = reinterpret_cast<float *>(lds + C::TB);
     unsigned int *flag = reinterpret_cast<unsigned int *>(lds + C::FL);
 
     const int lane = threadIdx.x & 63;
@@ -77,204 +122,296 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
     const bool active_me = r_me < a.R;
     const uint32_t g_me = a.replica_offset + (uint32_t)r_me;
     const int n = a.n;
-    const int rows_used = ((n + 3) >> 2) << 2;       // rows that can hold a proposal, in whole units
-    const int total_units = rows_used >> 2;
-    const int col0 = wave * C::S;                    // first column of this wave's slab
-    const int lr = lane & 15, lq = lane >> 4;        // MFMA lane coordinates: replica / k (or row quarter)
+    const int nbu = (n + 15) >> 4;                   // blocks that can hold a proposal
+    const int units_per_pass = 4 * nbu;
+    const bool last_tile_live = (C::M - 1) * 16 + wave < nbu;   // does this wave's last tile hold live columns
+    const int lr = lane & 15, lq = lane >> 4;        // MFMA lane coordinates: replica / k (or column quarter)
+    const int dr = lane >> 2, dq = lane & 3;         // DIAG lane coordinates: replica / column residue
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.Qm), 0, (C::NPAD + 1) * C::NPAD * 4, 0x00020000);
 
-    // ---- state bits -> xbits (one 16-bit word per row, bit r = replica r) via a byte image in the ring area
-    {
-        unsigned char *img = reinterpret_cast<unsigned char *>(lds);         // [16][NPAD]
-        for (int t = 0; t < NT; t += 4) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            if (!a.init && active_me)
-                philox4x32_10((uint32_t)((t >> 2) * 64 + lane), 0u, g_me, 1u, a.seed_lo, a.seed_hi, w);
+    // ---- state bits -> xr (one 16-bit word per block and replica): wave w packs replica w ----
+    for (int t = 0; t < NT; t += 4) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (!a.init && active_me)
+            philox4x32_10((uint32_t)((t >> 2) * 64 + lane), 0u, g_me, 1u, a.seed_lo, a.seed_hi, w);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int i = (t + c) * 64 + lane;
-                unsigned char bit = 0;
-                if (active_me && i < n) bit = a.init ? (a.init[(size_t)r_me * n + i] ? 1 : 0) : (unsigned char)(w[c] >> 31);
-                img[wave * C::NPAD + i] = bit;
-            }
+        for (int c = 0; c < 4; ++c) {
+            const int i = (t + c) * 64 + lane;
+            bool bit = false;
+            if (active_me && i < n) bit = a.init ? (a.init[(size_t)r_me * n + i] != 0) : ((w[c] >> 31) != 0);
+            const unsigned long long bal = __ballot(bit);
+            if (lane < 4) xr[((t + c) * 4 + lane) * 16 + wave] = (unsigned short)(bal >> (16 * lane));
         }
-        __syncthreads();
-        unsigned short mine[(C::NPAD + 1023) / 1024];
-#pragma unroll
-        for (int k = 0; k < (C::NPAD + 1023) / 1024; ++k) {
-            const int i = k * 1024 + (int)threadIdx.x;
-            unsigned int msk = 0;
-            if (i < C::NPAD)
-                for (int w2 = 0; w2 < 16; ++w2) msk |= (unsigned int)img[w2 * C::NPAD + i] << w2;
-            mine[k] = (unsigned short)msk;
-        }
-        __syncthreads();                                  // the image (ring area) is dead from here on
-#pragma unroll
-        for (int k = 0; k < (C::NPAD + 1023) / 1024; ++k) {
-            const int i = k * 1024 + (int)threadIdx.x;
-            if (i < C::NPAD) xbits[i] = mine[k];
-        }
-        if (threadIdx.x < 3) flag[threadIdx.x] = 0u;
-        __syncthreads();
     }
+    if (threadIdx.x < 3) flag[threadIdx.x] = 0u;
 
     // ---- fields: from the previous launch, or diag (the forced pass below then adds the rows with x = 1)
     f32x4acc acc[C::M];
     const bool fields_in = (a.flags & kDenseFieldsIn) != 0;
+    // the compiler waits for a load where its result is first used -- for these that would be a vmcnt wait in
+    // front of the MFMAs, which drains the ring's LDS-DMA queue with it: consume the loads here
+    auto pin_acc = [&]() {
 #pragma unroll
-    for (int tau = 0; tau < C::M; ++tau) {
-        const int j = col0 + tau * 16 + 4 * lq;          // 4 consecutive columns of replica lr
-        if (fields_in) {
-            const int rr = rbase + lr;
-            acc[tau] = (rr < a.R) ? *reinterpret_cast<const f32x4acc *>(a.fields + (size_t)rr * C::NPAD + j)
-                                  : f32x4acc{0, 0, 0, 0};
-        } else {
-            acc[tau] = *reinterpret_cast<const f32x4acc *>(a.Qm + (size_t)C::NPAD * C::NPAD + j);   // diagonal row
+        for (int tau = 0; tau < C::M; ++tau) asm volatile("" : "+v"(acc[tau]));
+    };
+    auto load_diag = [&]() {
+        // (through the buffer resource: flat pointers would sit in 2 VGPRs per tile across the whole kernel)
+#pragma unroll
+        for (int tau = 0; tau < C::M; ++tau) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (wave * 16 + 4 * lq) * 4,
+                                                                  C::NPAD * C::NPAD * 4 + tau * 1024, 0);
+            acc[tau] = f32x4acc{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
         }
+        pin_acc();
+    };
+    if (fields_in) {
+        const int rr = rbase + lr;
+#pragma unroll
+        for (int tau = 0; tau < C::M; ++tau)
+            acc[tau] = (rr < a.R) ? *reinterpret_cast<const f32x4acc *>(a.fields + (size_t)rr * C::NPAD + (tau * 16 + wave) * 16 + 4 * lq)
+                                  : f32x4acc{0, 0, 0, 0};
+        pin_acc();
+    } else {
+        load_diag();
     }
 
-    // ---- ring bookkeeping (wave-uniform, forced into SGPRs) ----
+    // ---- the passes of this launch: (sweep index, forced).  A forced pass takes no decisions, its "flips" are
+    // the set bits (s_k = x_k): it rebuilds the fields from the diagonal -- at the start, and at every re-sync,
+    // after which the same sweep index runs normally (same bookkeeping as K1 / K1w)
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    int issued = 0, processed = 0, issue_slot = 0, cur_slot = 0;
+    int gen_s = fields_in ? 0 : -1, gen_until = a.resync_first;
+    auto next_pass = [&](int &s_out, bool &force_out) -> bool {
+        if (gen_s >= a.num_sweeps) return false;
+        bool force = gen_s < 0;
+        if (gen_s >= 0 && a.resync > 0 && --gen_until == 0) { gen_until = a.resync + 1; force = true; }
+        s_out = gen_s; force_out = force;
+        gen_s = (force && gen_s >= 0) ? gen_s : gen_s + 1;
+        return true;
+    };
+    int total_passes = 0;
+    {
+        int s0, keep_s = gen_s, keep_u = gen_until; bool f0;
+        while (next_pass(s0, f0)) ++total_passes;
+        gen_s = keep_s; gen_until = keep_u;
+    }
+    const int total_units = total_passes * units_per_pass;
+
+    // ---- ring bookkeeping (wave-uniform, forced into SGPRs); the stream runs on across passes ----
+    int issued = 0, processed = 0, issue_slot = 0, cur_slot = 0, issue_row = 0;
     auto issue_unit = [&]() {
         if (issued < total_units) {
-            if (wave < C::G) {
+            if (wave < C::G && !K1M_DBG(1)) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     lds_dma_16(rsrc, lds + issue_slot * C::UNITB + k * C::ROWS + wave * 1024, lane * 16,
-                               (issued * 4 + k) * (C::NPAD * 4) + wave * 1024);
+                               (issue_row + k) * (C::NPAD * 4) + wave * 1024);
             }
             issued = uni(issued + 1);
+            issue_row = uni(issue_row + 4 >= units_per_pass * 4 ? 0 : issue_row + 4);
             issue_slot = uni((issue_slot + 1 == C::U) ? 0 : issue_slot + 1);
         }
     };
+    // the 16 x 16 couplings of block nb, gathered as C[k][q][m] = Q2[16nb + k][16nb + 4m + q]
+    auto issue_couplings = [&](int nb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int w = 64 * i + lane, k = w >> 4, q = (w >> 2) & 3, m = w & 3;
+            lds_dma_4(rsrc, lds + C::CB + i * 256, ((16 * nb + k) * C::NPAD + 16 * nb + 4 * m + q) * 4, 0);
+        }
+    };
+    auto draw_thresholds = [&](int s_pass, int grp) {
+        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
+            a.temps[a.temps_per_replica ? (active_me ? r_me : 0) : s_pass])));
+        uint32_t w4[4];
+        philox4x32_10((uint32_t)(grp * 64 + lane), (uint32_t)s_pass + a.sweep_offset, g_me, 0u, a.seed_lo, a.seed_hi, w4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float th = neglog_u(w4[c]) * T;
+            if (grp * 256 + c * 64 + lane >= n || !active_me) th = -INFINITY;
+            thr[wave * C::THRS + c * 64 + lane] = th;
+        }
+    };
+    auto dump_tile = [&](int tile) {                 // acc[tile] -> T[replica][column], for the wave's own DIAG
+        static_for<0, C::M>([&](auto tc) {
+            constexpr int tau = decltype(tc)::value;
+            if (tau == tile) *reinterpret_cast<f32x4acc *>(Tbuf + lr * 20 + 4 * lq) = acc[tau];
+        });
+    };
 
     unsigned long long accepted = 0;
-    int until_resync = a.resync_first;
-    // pass -1 is the forced field-initialisation pass (s_k = x_k, no decisions); it also serves re-syncs
-    for (int s = (fields_in ? 0 : -1); s < a.num_sweeps; ++s) {
-        bool force = (s < 0);
-        if (s >= 0 && a.resync > 0 && --until_resync == 0) {
-            // exact re-initialisation: acc = diag, then one forced pass, then redo this sweep index normally
-            until_resync = a.resync + 1;                  // the redo of this s decrements once more
-#pragma unroll
-            for (int tau = 0; tau < C::M; ++tau)
-                acc[tau] = *reinterpret_cast<const f32x4acc *>(a.Qm + (size_t)C::NPAD * C::NPAD + col0 + tau * 16 + 4 * lq);
-            force = true;
-        }
-        const float T_me = force ? 1.0f
-                                 : __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
-                                       a.temps[a.temps_per_replica ? (active_me ? r_me : 0) : s])));
-        // prime the ring for this pass
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        issued = 0; processed = 0; issue_slot = 0; cur_slot = 0;
-        issue_unit();
-        issue_unit();
 
-        bool done = false;
-#pragma unroll 1
-        for (int wstar = 0; wstar < 16 && !done; ++wstar) {
-            static_for<0, C::M>([&](auto tc) {
-                constexpr int taustar = decltype(tc)::value;
-#pragma unroll 1
-                for (int qstar = 0; qstar < 4 && !done; ++qstar) {
-                    const int R0 = wstar * C::S + taustar * 16 + qstar * 4;
-                    if (R0 >= rows_used) { done = true; break; }        // wave-uniform
-                    const int u = R0 >> 2;
-                    // thresholds of the next four slots (256 rows): wave w draws for replica w
-                    if (!force && (R0 & 255) == 0) {
-                        uint32_t w4[4];
-                        philox4x32_10((uint32_t)((R0 >> 8) * 64 + lane), (uint32_t)s + a.sweep_offset, g_me, 0u,
-                                      a.seed_lo, a.seed_hi, w4);
+    // DIAG of block nb (by its owner wave): decisions of 16 rows x 16 replicas.  gbn = running block count (picks
+    // the S buffer / flag word); pre_unit != nullptr: first apply the four rows of that ring unit with the signs
+    // of the previous block's last unit (the accumulator copy in T is one unit old).
+    auto diag = [&](int nb, bool force, int gbn, const char *pre_unit) {
+        const int R0 = 16 * nb;
+        const unsigned int xw = xr[nb * 16 + dr];
+        float sown[4];
+        if (!force && !K1M_DBG(4)) {
+            float tq[4], hq[4];
+            unsigned int sx[4];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            float thr = neglog_u(w4[c]) * T_me;
-                            if (R0 + c * 64 + lane >= n || !active_me) thr = -INFINITY;
-                            thrbuf[(c * 64 + lane) * 16 + wave] = thr;
-                        }
-                    }
-                    // rendezvous A: ring unit u has landed (every wave waited for its own pieces); also
-                    // publishes the thresholds written above
-                    if (issued - processed - 1 >= 1) {
-                        if (wave < C::G) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 1 younger unit in flight
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    issue_unit();                                         // into the slot unit u-1 vacated
-                    const char *unit = lds + cur_slot * C::UNITB;
-                    float *Su = Sbuf + (u & 1) * 64;
-
-                    if (wave == wstar) {                                  // wave-uniform
-                        const bool mine = (lq == qstar);                  // the 16 lanes holding these fields
-                        const float *urow = reinterpret_cast<const float *>(unit);
-                        constexpr int RS = C::ROWS / 4;                   // row stride in floats
-                        float t0 = acc[taustar][0], t1 = acc[taustar][1], t2 = acc[taustar][2], t3 = acc[taustar][3];
-                        const unsigned int x0w = xbits[R0], x1w = xbits[R0 + 1], x2w = xbits[R0 + 2], x3w = xbits[R0 + 3];
-                        const int x0 = (x0w >> lr) & 1, x1 = (x1w >> lr) & 1, x2 = (x2w >> lr) & 1, x3 = (x3w >> lr) & 1;
-                        float s0, s1, s2, s3;
-                        int a0, a1, a2, a3;
-                        if (force) {
-                            s0 = (float)x0; s1 = (float)x1; s2 = (float)x2; s3 = (float)x3;
-                            a0 = a1 = a2 = a3 = 0;
-                        } else {
-                            const int ib = ((R0 >> 6) & 3) * 64 + (R0 & 63);
-                            const float h0 = thrbuf[(ib + 0) * 16 + lr], h1 = thrbuf[(ib + 1) * 16 + lr];
-                            const float h2 = thrbuf[(ib + 2) * 16 + lr], h3 = thrbuf[(ib + 3) * 16 + lr];
-                            // couplings inside the unit: c_kk' = Q2[R0+k][R0+k'] (row k of the unit, column R0+k')
-                            const float c01 = urow[0 * RS + R0 + 1], c02 = urow[0 * RS + R0 + 2], c03 = urow[0 * RS + R0 + 3];
-                            const float c12 = urow[1 * RS + R0 + 2], c13 = urow[1 * RS + R0 + 3];
-                            const float c23 = urow[2 * RS + R0 + 3];
-                            a0 = mine && ((x0 ? -t0 : t0) < h0);
-                            s0 = a0 ? (x0 ? -1.0f : 1.0f) : 0.0f;
-                            t1 = __fmaf_rn(c01, s0, t1);
-                            a1 = mine && ((x1 ? -t1 : t1) < h1);
-                            s1 = a1 ? (x1 ? -1.0f : 1.0f) : 0.0f;
-                            t2 = __fmaf_rn(c12, s1, __fmaf_rn(c02, s0, t2));
-                            a2 = mine && ((x2 ? -t2 : t2) < h2);
-                            s2 = a2 ? (x2 ? -1.0f : 1.0f) : 0.0f;
-                            t3 = __fmaf_rn(c23, s2, __fmaf_rn(c13, s1, __fmaf_rn(c03, s0, t3)));
-                            a3 = mine && ((x3 ? -t3 : t3) < h3);
-                            s3 = a3 ? (x3 ? -1.0f : 1.0f) : 0.0f;
-                        }
-                        if (mine) { Su[0 * 16 + lr] = s0; Su[1 * 16 + lr] = s1; Su[2 * 16 + lr] = s2; Su[3 * 16 + lr] = s3; }
-                        // new state bits of the four rows: ballots over the 16 active lanes of this quarter
-                        const int sh = 16 * qstar;
-                        const unsigned long long b0 = __ballot(mine && (x0 ^ a0)), b1 = __ballot(mine && (x1 ^ a1));
-                        const unsigned long long b2 = __ballot(mine && (x2 ^ a2)), b3 = __ballot(mine && (x3 ^ a3));
-                        const unsigned long long f0 = __ballot(a0), f1 = __ballot(a1), f2 = __ballot(a2), f3 = __ballot(a3);
-                        const unsigned long long nz = __ballot(mine && ((s0 != 0.0f) | (s1 != 0.0f) | (s2 != 0.0f) | (s3 != 0.0f)));
-                        if (mine && lr == 0) {
-                            if (!force) {
-                                xbits[R0] = (unsigned short)(b0 >> sh); xbits[R0 + 1] = (unsigned short)(b1 >> sh);
-                                xbits[R0 + 2] = (unsigned short)(b2 >> sh); xbits[R0 + 3] = (unsigned short)(b3 >> sh);
-                            }
-                            flag[u & 1] = (nz != 0) ? 1u : 0u;
-                        }
-                        accepted += (unsigned long long)(__popcll(f0) + __popcll(f1) + __popcll(f2) + __popcll(f3));
-                    }
-                    // rendezvous B: the signs of unit u are published
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (__builtin_amdgcn_readfirstlane((int)flag[u & 1]) != 0) {
-                        const float b = Su[lq * 16 + lr];                                   // B[k = lq][r = lr]
-                        const char *arow = unit + lq * C::ROWS + (col0 + lr) * 4;           // A[i = lr][k = lq]
+            for (int m = 0; m < 4; ++m) {
+                tq[m] = Tbuf[dr * 20 + 4 * m + dq];
+                hq[m] = thr[dr * C::THRS + ((R0 + 4 * m + dq) & 255)];
+                sx[m] = (xw << (31 - 4 * m - dq)) & 0x80000000u;
+                sown[m] = 0.0f;
+            }
+            if (pre_unit) {
+                const float *Sp = Sbuf + ((gbn - 1) & 1) * 256 + 3 * 64 + dr;
 #pragma unroll
-                        for (int tau = 0; tau < C::M; ++tau) {
-                            const float av = *reinterpret_cast<const float *>(arow + tau * 64);
-                            acc[tau] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[tau], 0, 0, 0);
-                        }
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float sv = Sp[kk * 16];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float qv = *reinterpret_cast<const float *>(pre_unit + kk * C::ROWS + (R0 + 4 * m + dq) * 4);
+                        tq[m] = __fmaf_rn(qv, sv, tq[m]);
                     }
-                    cur_slot = uni((cur_slot + 1 == C::U) ? 0 : cur_slot + 1);
-                    processed = uni(processed + 1);
                 }
+            }
+            static_for<0, 16>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int mk = k >> 2, qk = k & 3;
+                const f32x4acc c4 = *reinterpret_cast<const f32x4acc *>(Cbuf + k * 16 + dq * 4);
+                const bool d = __uint_as_float(__float_as_uint(tq[mk]) ^ sx[mk]) < hq[mk];
+                const float so = d ? __uint_as_float(0x3f800000u ^ sx[mk]) : 0.0f;
+                const float sk = quad_bcast<qk>(so);
+                if (dq == qk) sown[mk] = so;
+#pragma unroll
+                for (int m = mk; m < 4; ++m) tq[m] = __fmaf_rn(c4[m], sk, tq[m]);
             });
+        } else if (!force) {                          // (diagnostic timing build: no decisions)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sown[m] = 0.0f;
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sown[m] = ((xw >> (4 * m + dq)) & 1u) ? 1.0f : 0.0f;
         }
-        if (force && s >= 0) --s;                     // the re-sync pass does not consume a sweep index
+        float *Sn = Sbuf + (gbn & 1) * 256;
+        unsigned int nz = 0, word = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            Sn[m * 64 + dq * 16 + dr] = sown[m];
+            const unsigned long long bal = __ballot(sown[m] != 0.0f);
+            if (bal) nz |= 1u << m;
+            if (!force) {
+                accepted += (unsigned long long)__popcll(bal);
+                word |= (sown[m] != 0.0f ? 1u : 0u) << (4 * m + dq);
+            }
+        }
+        if (!force) {
+            word |= quad_perm<0xB1>(word);
+            word |= quad_perm<0x4E>(word);
+            if (dq == 0) xr[nb * 16 + dr] = (unsigned short)(xw ^ word);
+        }
+        if (lane == 0) flag[gbn & 1] = nz;
+    };
+
+    int cur_s = 0, nxt_s = 0;
+    bool cur_force = false, nxt_force = false;
+    bool have_cur = next_pass(cur_s, cur_force);
+    __syncthreads();                                  // xr / flag initialised
+    if (have_cur) {
+        // prologue: thresholds + couplings of block 0, the first two ring units, DIAG(0) by wave 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only LDS-DMA is in the VM queue
+        if (!cur_force) {
+            draw_thresholds(cur_s, 0);
+            if (wave == 15) { issue_couplings(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
+        issue_unit();
+        issue_unit();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0) {
+            if (!cur_force) dump_tile(0);
+            diag(0, cur_force, 0, nullptr);
+        }
+    }
+    int gb = 0;                                       // running block count
+#ifdef MI_K1M_TICKS
+    unsigned long long tick_ = __builtin_amdgcn_s_memtime(), t_wait[4] = {0, 0, 0, 0}, t_body[4] = {0, 0, 0, 0}, t_diag = 0, t_thr = 0;
+#define K1M_TICK(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); var += now_ - tick_; tick_ = now_; } while (0)
+#else
+#define K1M_TICK(var) do { } while (0)
+#endif
+    while (have_cur) {
+        const bool have_nxt = next_pass(nxt_s, nxt_force);
+        if (cur_force && cur_s >= 0) load_diag();     // re-sync: rebuild from the diagonal
+#pragma unroll 1
+        for (int b = 0; b < nbu; ++b) {
+            const bool wrap = (b + 1 == nbu);
+            const bool nb_valid = !wrap || have_nxt;
+            const int nb = wrap ? 0 : b + 1;
+            const int np_s = wrap ? nxt_s : cur_s;
+            const bool np_force = wrap ? nxt_force : cur_force;
+            const bool own_next = nb_valid && wave == (nb & 15);
+            unsigned int nzw = 0;                     // bit g: unit g of this block has a flip in some replica
+            static_for<0, 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                // rendezvous: ring unit landed (every loader waited for its own pieces), previous unit consumed,
+                // everything the owner of this block published is visible
+                if (wave < C::G) {
+                    if (issued - processed >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 1 younger unit in flight
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (g == 3) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wave 15: the couplings, issued 3 units ago
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                K1M_TICK(t_wait[g]);
+                issue_unit();                                         // into the slot the previous unit vacated
+                const char *unit = lds + cur_slot * C::UNITB;
+                if constexpr (g == 0) {
+                    nzw = (unsigned int)__builtin_amdgcn_readfirstlane((int)flag[gb & 1]);
+                    if (nb_valid && !np_force) {
+                        if (wave == 15) issue_couplings(nb);
+                        if ((nb & 15) == 0) {
+                            // (opaque copy: LICM otherwise hoists the whole Philox block out of this branch and
+                            // runs it once per BLOCK in all 16 waves)
+                            int grp = nb >> 4;
+                            asm volatile("" : "+s"(grp));
+                            draw_thresholds(np_s, grp);
+                        }
+                    }
+                }
+                if constexpr (g == 3) {
+                    if (own_next) {
+#ifdef MI_K1M_TICKS
+                        unsigned long long keep = 0; K1M_TICK(keep); t_body[g] += keep;
+#endif
+                        diag(nb, np_force, gb + 1, unit);
+                        K1M_TICK(t_diag);
+                    }
+                }
+                if (((nzw >> g) & 1u) && !K1M_DBG(8)) {
+                    const float bv = Sbuf[(gb & 1) * 256 + g * 64 + lane];               // B[k = lq][r = lr]
+                    const char *arow = unit + lq * C::ROWS + (wave * 16 + lr) * 4;       // A[i = lr][k = lq]
+                    // all A operands first, then the MFMAs back to back (one read -> wait -> MFMA per tile is a
+                    // latency chain of 11 LDS round trips per unit and wave)
+                    float av[C::M];
+#pragma unroll
+                    for (int tau = 0; tau < C::M; ++tau) av[tau] = *reinterpret_cast<const float *>(arow + tau * 1024);
+#pragma unroll
+                    for (int tau = 0; tau < C::M; ++tau) asm volatile("" : "+v"(av[tau]));
+#pragma unroll
+                    for (int tau = 0; tau < C::M; ++tau) {
+                        // (n_pad - n < 256 columns = one tile per wave: only the last tile can be all padding)
+                        if (tau < C::M - 1 || last_tile_live)
+                            acc[tau] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tau], bv, acc[tau], 0, 0, 0);
+                    }
+                }
+                if constexpr (g == 2) {
+                    if (own_next && !np_force) dump_tile(nb >> 4);
+                }
+                cur_slot = uni((cur_slot + 1 == C::U) ? 0 : cur_slot + 1);
+                processed = uni(processed + 1);
+                K1M_TICK(t_body[g]);
+            });
+            gb = uni(gb + 1);
+        }
+        cur_s = nxt_s; cur_force = nxt_force; have_cur = have_nxt;
     }
 
     // ---- results: states (wave w = replica w), cached fields, energies, flip count, next kernel ----
@@ -284,7 +421,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
         uint8_t *dst = a.states + (size_t)r_me * n;
         for (int t = 0; t < NT; ++t) {
             const int i = t * 64 + lane;
-            if (i < n) dst[i] = (uint8_t)((xbits[i] >> wave) & 1);
+            if (i < n) dst[i] = (uint8_t)((xr[(i >> 4) * 16 + wave] >> (i & 15)) & 1);
         }
     }
     if (a.flags & kDenseFieldsOut) {
@@ -292,9 +429,15 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
         if (rr < a.R) {
 #pragma unroll
             for (int tau = 0; tau < C::M; ++tau)
-                *reinterpret_cast<f32x4acc *>(a.fields + (size_t)rr * C::NPAD + col0 + tau * 16 + 4 * lq) = acc[tau];
+                *reinterpret_cast<f32x4acc *>(a.fields + (size_t)rr * C::NPAD + (tau * 16 + wave) * 16 + 4 * lq) = acc[tau];
         }
     }
+#ifdef MI_K1M_TICKS
+    if (lane == 0 && blockIdx.x == 0) {              // stats[4..7] / [8..11]: wave 1's wait / body time per unit phase
+        if (wave == 1) for (int g = 0; g < 4; ++g) { atomicAdd(&a.stats[4 + g], t_wait[g]); atomicAdd(&a.stats[8 + g], t_body[g]); }
+        atomicAdd(&a.stats[12], t_diag);              // all owners of workgroup 0
+    }
+#endif
     if (lane == 0 && accepted) {
         atomicAdd(&a.stats[1], accepted);
         atomicAdd(&flag[2], (unsigned int)accepted);
@@ -302,7 +445,10 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
     if (!(a.flags & kDenseNoEnergy) && active_me) {
         // exact fp64 energy from the slot-permuted matrix (same evaluator as K1 / K1w)
         uint64_t xb = 0;
-        for (int t = 0; t < NT; ++t) xb |= (uint64_t)((xbits[t * 64 + lane] >> wave) & 1) << t;
+        for (int t = 0; t < NT; ++t) {
+            const int i = t * 64 + lane;
+            xb |= (uint64_t)((xr[(i >> 4) * 16 + wave] >> (i & 15)) & 1) << t;
+        }
         const int diag_row = ((n + 63) >> 6) * 64;
         const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.Qp), 0, (diag_row + 1) * (NT * 256), 0x00020000);

@@ -218,7 +218,8 @@ struct DenseArgs {
     int chunk_index;        // position of this launch in its run: its mode word is ctrl[kCtrlModes + chunk_index]
     unsigned int mode_up_flips;   // launch-wide accepted flips at or above which the NEXT launch uses K1m
     int ondemand_flips;     // K1w: sweeps whose predecessor had fewer accepted flips per workgroup run on demand (0 = never)
-    int debug;              // diagnostic timing builds only: bit0 = skip LDS-DMA, bit1 = accept nothing
+    int debug;              // diagnostic timing builds only: bit0 = skip LDS-DMA, bit1 = accept nothing (K1w);
+                            // K1m: bit2 = no decision chain, bit3 = no MFMAs
 };
 
 constexpr int kDenseFieldsIn = 1;    // start from the cached fields in DenseArgs::fields (no re-initialisation)
