@@ -37,8 +37,9 @@ with Problem.dense(Qs) as p:
                 arm, ms, ms / a.sweeps, ms * 1e-3 * 2.4e9 / units, info["accepted"] / info["proposals"],
                 a.replicas * a.sweeps * n / ms * 1e3, p.kernel_name()), flush=True)
             ds = p.debug_stats()
-            if ds[4:13].any():                     # a build with -DMI_K1M_TICKS: s_memtime ticks of wave 1, workgroup 0
+            if ds[4:14].any():                     # a build with -DMI_K1M_TICKS: s_memtime ticks of the wave debug>>8, workgroup 0
                 per = float(units) / 4.0
-                print("     ticks per unit phase g=0..3: wait %s   body %s   DIAG per block %.0f" % (
+                print("     wave %d ticks per unit phase g=0..3: wait %s | after-barrier part: total %s of which bookkeeping %.0f DIAG %.0f (avg per unit)" % (
+                    int(dict(kv.split("=") for kv in arm.split(","))["debug"]) >> 8,
                     " ".join("%6.0f" % (ds[4 + g] / per) for g in range(4)),
-                    " ".join("%6.0f" % (ds[8 + g] / per) for g in range(4)), ds[12] / per), flush=True)
+                    " ".join("%6.0f" % (ds[8 + g] / per) for g in range(4)), ds[12] / units, ds[13] / units), flush=True)

@@ -54,6 +54,8 @@ namespace mi_sa_impl {
 namespace {
 
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const float lds_f32;
+typedef __attribute__((address_space(3))) const f32x4acc lds_f32x4;
 
 template <int NT>
 struct MfCfg {
@@ -63,14 +65,15 @@ struct MfCfg {
     static constexpr int ROWS = (NPAD + 16) * 4;     // LDS row stride: +64 B makes the A reads conflict-free
     static constexpr int UNITB = 4 * ROWS;           // a unit = 4 rows = the K of one MFMA
     static constexpr int U = 3;
-    static constexpr int G = NT / 4;                 // 1 KiB pieces per row = waves that load the ring
+    static constexpr int G = NT / 4;                 // 1 KiB pieces per row
     static constexpr int RING = U * UNITB;
     static constexpr int THRS = 260;                 // floats per replica: 256 rows + 4 (conflict-free reads)
     static constexpr int THR = RING;                 // float thr[16][THRS]
     static constexpr int XR = THR + 16 * THRS * 4;   // uint16 xr[NB][16]: bit k = x of row 16*block + k
     static constexpr int SB = XR + NB * 16 * 2;      // float S[2][4][64]: B operands of a block's 4 units
     static constexpr int CB = SB + 2 * 256 * 4;      // float C[16][4][4]: coupling block, [k][q][m]
-    static constexpr int TB = CB + 256 * 4;          // float T[16][20]: accumulator tile on its way to DIAG
+    static constexpr int EB = CB + 256 * 4;          // float E[16][4][4]: previous block's rows x this block's columns
+    static constexpr int TB = EB + 256 * 4;          // float T[16][20]: accumulator tile on its way to DIAG
     static constexpr int FL = TB + 16 * 20 * 4;      // uint32 flag[2] (units with a flip), wg_flips
     static constexpr int TOTAL = FL + 16;
     static constexpr bool ok = TOTAL <= 160 * 1024 && G <= 15;
@@ -112,6 +115,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
     unsigned short *xr = reinterpret_cast<unsigned short *>(lds + C::XR);
     float *Sbuf = reinterpret_cast<float *>(lds + C::SB);
     float *Cbuf = reinterpret_cast<float *>(lds + C::CB);
+    float *Ebuf = reinterpret_cast<float *>(lds + C::EB);
     float *Tbuf = reinterpret_cast<float *>(lds + C::TB);
     unsigned int *flag = reinterpret_cast<unsigned int *>(lds + C::FL);
 
@@ -127,6 +131,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
     const bool last_tile_live = (C::M - 1) * 16 + wave < nbu;   // does this wave's last tile hold live columns
     const int lr = lane & 15, lq = lane >> 4;        // MFMA lane coordinates: replica / k (or column quarter)
     const int dr = lane >> 2, dq = lane & 3;         // DIAG lane coordinates: replica / column residue
+    const bool loader = wave < 4;                    // waves 0..3 stream the ring (row = wave of every unit)
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.Qm), 0, (C::NPAD + 1) * C::NPAD * 4, 0x00020000);
@@ -200,26 +205,29 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
 
     // ---- ring bookkeeping (wave-uniform, forced into SGPRs); the stream runs on across passes ----
     int issued = 0, processed = 0, issue_slot = 0, cur_slot = 0, issue_row = 0;
+    // (four loader waves -- one per SIMD -- bring in one row of the unit each, all G pieces of it: the bookkeeping
+    // of the stream is then paid once per SIMD and overlaps the MFMAs of the three other waves there; every
+    // instruction in this loop costs its issue slot in all waves that execute it)
     auto issue_unit = [&]() {
         if (issued < total_units) {
-            if (wave < C::G && !K1M_DBG(1)) {
+            if (!K1M_DBG(1)) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    lds_dma_16(rsrc, lds + issue_slot * C::UNITB + k * C::ROWS + wave * 1024, lane * 16,
-                               (issue_row + k) * (C::NPAD * 4) + wave * 1024);
+                for (int p = 0; p < C::G; ++p)
+                    lds_dma_16(rsrc, lds + issue_slot * C::UNITB + wave * C::ROWS + p * 1024, lane * 16,
+                               (issue_row + wave) * (C::NPAD * 4) + p * 1024);
             }
             issued = uni(issued + 1);
             issue_row = uni(issue_row + 4 >= units_per_pass * 4 ? 0 : issue_row + 4);
             issue_slot = uni((issue_slot + 1 == C::U) ? 0 : issue_slot + 1);
         }
     };
-    // the 16 x 16 couplings of block nb, gathered as C[k][q][m] = Q2[16nb + k][16nb + 4m + q]
-    auto issue_couplings = [&](int nb) {
+    // a 16 x 16 block of Q2, gathered (and transposed on the way) as dst[k][q][m] = Q2[16rb + k][16cb + 4m + q]
+    auto issue_block = [&](int dst, int rb, int cb) {
+        // word 64i + lane of dst: k = 4i + (lane >> 4), q = (lane >> 2) & 3, m = lane & 3
+        const int lane_off = ((lane >> 4) * C::NPAD + 4 * (lane & 3) + ((lane >> 2) & 3)) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int w = 64 * i + lane, k = w >> 4, q = (w >> 2) & 3, m = w & 3;
-            lds_dma_4(rsrc, lds + C::CB + i * 256, ((16 * nb + k) * C::NPAD + 16 * nb + 4 * m + q) * 4, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+            lds_dma_4(rsrc, lds + dst + i * 256, lane_off, ((16 * rb + 4 * i) * C::NPAD + 16 * cb) * 4);
     };
     auto draw_thresholds = [&](int s_pass, int grp) {
         const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
@@ -242,72 +250,98 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
 
     unsigned long long accepted = 0;
 
-    // DIAG of block nb (by its owner wave): decisions of 16 rows x 16 replicas.  gbn = running block count (picks
-    // the S buffer / flag word); pre_unit != nullptr: first apply the four rows of that ring unit with the signs
-    // of the previous block's last unit (the accumulator copy in T is one unit old).
-    auto diag = [&](int nb, bool force, int gbn, const char *pre_unit) {
-        const int R0 = 16 * nb;
-        const unsigned int xw = xr[nb * 16 + dr];
-        float sown[4];
-        if (!force && !K1M_DBG(4)) {
-            float tq[4], hq[4];
-            unsigned int sx[4];
+    // ---- DIAG of block nb (by its owner wave): the decisions of 16 rows x 16 replicas, in four pieces that run
+    // in the four units of the block BEFORE it (state in d_*; only the owner's copy means anything):
+    //   begin   the accumulator tile as it is at the start of the previous block -> t (DIAG lane layout)
+    //   pre     the previous block's 16 rows applied by hand: its signs S are known, its couplings to this
+    //           block's columns come from E -- the same fmaf chain the MFMAs apply to the accumulators meanwhile
+    //   steps   the sequential walk over the 16 rows
+    //   end     publishes the B operands, the state bits and the "unit has a flip" word
+    float d_tq[4], d_hq[4], d_sown[4];
+    unsigned int d_sx[4], d_xw = 0;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                tq[m] = Tbuf[dr * 20 + 4 * m + dq];
-                hq[m] = thr[dr * C::THRS + ((R0 + 4 * m + dq) & 255)];
-                sx[m] = (xw << (31 - 4 * m - dq)) & 0x80000000u;
-                sown[m] = 0.0f;
-            }
-            if (pre_unit) {
-                const float *Sp = Sbuf + ((gbn - 1) & 1) * 256 + 3 * 64 + dr;
+    for (int m = 0; m < 4; ++m) { d_tq[m] = 0.0f; d_hq[m] = 0.0f; d_sown[m] = 0.0f; d_sx[m] = 0u; }
+    auto diag_begin = [&](int nb) {
+        d_xw = xr[nb * 16 + dr];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const float sv = Sp[kk * 16];
+        for (int m = 0; m < 4; ++m) {
+            d_tq[m] = Tbuf[dr * 20 + 4 * m + dq];
+            d_sx[m] = (d_xw << (31 - 4 * m - dq)) & 0x80000000u;
+            d_sown[m] = 0.0f;
+        }
+    };
+    // (the LDS bases go through an opaque copy so that every access below is base register + immediate offset:
+    // left alone, the compiler materialises one address VGPR per row, hoists them all out of the loops, spills
+    // them -- and every scratch reload is a vmcnt(0) wait that drains the ring's DMA queue)
+    auto opaque = [](const float *p) {
+        lds_f32 *q = (lds_f32 *)p;
+        asm volatile("" : "+v"(q));
+        return q;
+    };
+    auto diag_pre = [&](int gb_cur, auto k0c, auto k1c) {
+        constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+        lds_f32 *Sp = opaque(Sbuf + (gb_cur & 1) * 256 + dr);
+        lds_f32 *Ep = opaque(Ebuf + dq * 4);
+        static_for<K0, K1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const f32x4acc e4 = *(lds_f32x4 *)(Ep + k * 16);
+            const float sv = Sp[(k >> 2) * 64 + (k & 3) * 16];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const float qv = *reinterpret_cast<const float *>(pre_unit + kk * C::ROWS + (R0 + 4 * m + dq) * 4);
-                        tq[m] = __fmaf_rn(qv, sv, tq[m]);
-                    }
-                }
-            }
-            static_for<0, 16>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                constexpr int mk = k >> 2, qk = k & 3;
-                const f32x4acc c4 = *reinterpret_cast<const f32x4acc *>(Cbuf + k * 16 + dq * 4);
-                const bool d = __uint_as_float(__float_as_uint(tq[mk]) ^ sx[mk]) < hq[mk];
-                const float so = d ? __uint_as_float(0x3f800000u ^ sx[mk]) : 0.0f;
-                const float sk = quad_bcast<qk>(so);
-                if (dq == qk) sown[mk] = so;
+            for (int m = 0; m < 4; ++m) d_tq[m] = __fmaf_rn(e4[m], sv, d_tq[m]);
+        });
+    };
+    auto diag_thresholds = [&](int nb) {
 #pragma unroll
-                for (int m = mk; m < 4; ++m) tq[m] = __fmaf_rn(c4[m], sk, tq[m]);
-            });
-        } else if (!force) {                          // (diagnostic timing build: no decisions)
+        for (int m = 0; m < 4; ++m) d_hq[m] = thr[dr * C::THRS + ((16 * nb + 4 * m + dq) & 255)];
+    };
+    auto diag_steps = [&](auto k0c, auto k1c) {
+        constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+        if (K1M_DBG(4)) return;
+        lds_f32 *Cp = opaque(Cbuf + dq * 4);
+        f32x4acc cq[3];                                   // rows k, k+1, k+2: two LDS round trips stay in flight
+        cq[0] = *(lds_f32x4 *)(Cp + K0 * 16);
+        cq[1] = *(lds_f32x4 *)(Cp + (K0 + 1) * 16);
+        static_for<K0, K1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int mk = k >> 2, qk = k & 3;
+            if constexpr (k + 2 < K1) cq[(k + 2 - K0) % 3] = *(lds_f32x4 *)(Cp + (k + 2) * 16);
+            const f32x4acc c4 = cq[(k - K0) % 3];
+            const bool d = __uint_as_float(__float_as_uint(d_tq[mk]) ^ d_sx[mk]) < d_hq[mk];
+            const float so = d ? __uint_as_float(0x3f800000u ^ d_sx[mk]) : 0.0f;
+            const float sk = quad_bcast<qk>(so);
+            if (dq == qk) d_sown[mk] = so;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) sown[m] = 0.0f;
-        } else {
+            for (int m = mk; m < 4; ++m) d_tq[m] = __fmaf_rn(c4[m], sk, d_tq[m]);    // (m = mk: dead fields, see top)
+        });
+    };
+    auto diag_end = [&](int nb, bool force, int gbn) {
+        if (force) {
+            d_xw = xr[nb * 16 + dr];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) sown[m] = ((xw >> (4 * m + dq)) & 1u) ? 1.0f : 0.0f;
+            for (int m = 0; m < 4; ++m) d_sown[m] = ((d_xw >> (4 * m + dq)) & 1u) ? 1.0f : 0.0f;
         }
         float *Sn = Sbuf + (gbn & 1) * 256;
         unsigned int nz = 0, word = 0;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            Sn[m * 64 + dq * 16 + dr] = sown[m];
-            const unsigned long long bal = __ballot(sown[m] != 0.0f);
+            Sn[m * 64 + dq * 16 + dr] = d_sown[m];
+            const unsigned long long bal = __ballot(d_sown[m] != 0.0f);
             if (bal) nz |= 1u << m;
             if (!force) {
                 accepted += (unsigned long long)__popcll(bal);
-                word |= (sown[m] != 0.0f ? 1u : 0u) << (4 * m + dq);
+                word |= (d_sown[m] != 0.0f ? 1u : 0u) << (4 * m + dq);
             }
         }
         if (!force) {
             word |= quad_perm<0xB1>(word);
             word |= quad_perm<0x4E>(word);
-            if (dq == 0) xr[nb * 16 + dr] = (unsigned short)(xw ^ word);
+            if (dq == 0) xr[nb * 16 + dr] = (unsigned short)(d_xw ^ word);
         }
         if (lane == 0) flag[gbn & 1] = nz;
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I8 = std::integral_constant<int, 8>;
+    using I16 = std::integral_constant<int, 16>;
 
     int cur_s = 0, nxt_s = 0;
     bool cur_force = false, nxt_force = false;
@@ -316,17 +350,23 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
     if (have_cur) {
         // prologue: thresholds + couplings of block 0, the first two ring units, DIAG(0) by wave 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only LDS-DMA is in the VM queue
-        if (!cur_force) {
-            draw_thresholds(cur_s, 0);
-            if (wave == 15) { issue_couplings(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (!cur_force) draw_thresholds(cur_s, 0);
+        if (wave == 15) {
+            if (!cur_force) issue_block(C::CB, 0, 0);
+            issue_block(C::EB, 0, nbu > 1 ? 1 : 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        issue_unit();
-        issue_unit();
+        if (loader) { issue_unit(); issue_unit(); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wave == 0) {
-            if (!cur_force) dump_tile(0);
-            diag(0, cur_force, 0, nullptr);
+            if (!cur_force) {
+                dump_tile(0);
+                diag_begin(0);
+                diag_thresholds(0);
+                diag_steps(I0{}, I16{});
+            }
+            diag_end(0, cur_force, 0);
         }
     }
     int gb = 0;                                       // running block count
@@ -336,6 +376,17 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
 #else
 #define K1M_TICK(var) do { } while (0)
 #endif
+    float av[C::M], bv = 0.0f;                        // MFMA operands of the current unit
+#pragma unroll
+    for (int tau = 0; tau < C::M; ++tau) av[tau] = 0.0f;
+    auto run_mfmas = [&]() {
+#pragma unroll
+        for (int tau = 0; tau < C::M; ++tau) {
+            // (n_pad - n < 256 columns = one tile per wave: only the last tile can be all padding)
+            if (tau < C::M - 1 || last_tile_live)
+                acc[tau] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tau], bv, acc[tau], 0, 0, 0);
+        }
+    };
     while (have_cur) {
         const bool have_nxt = next_pass(nxt_s, nxt_force);
         if (cur_force && cur_s >= 0) load_diag();     // re-sync: rebuild from the diagonal
@@ -347,67 +398,62 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
             const int np_s = wrap ? nxt_s : cur_s;
             const bool np_force = wrap ? nxt_force : cur_force;
             const bool own_next = nb_valid && wave == (nb & 15);
+            const bool own_chain = own_next && !np_force;
             unsigned int nzw = 0;                     // bit g: unit g of this block has a flip in some replica
             static_for<0, 4>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 // rendezvous: ring unit landed (every loader waited for its own pieces), previous unit consumed,
                 // everything the owner of this block published is visible
-                if (wave < C::G) {
-                    if (issued - processed >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 1 younger unit in flight
+                if ((loader)) {
+                    if (issued - processed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::G) : "memory");   // 1 younger unit in flight
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else if (g == 3) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wave 15: the couplings, issued 3 units ago
+                } else if ((g == 0 || g == 2) && (wave == 15)) {
+                    // wave 15: E of this block (issued in unit 2 of the previous one) / C of the next (in unit 0)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 K1M_TICK(t_wait[g]);
-                issue_unit();                                         // into the slot the previous unit vacated
                 const char *unit = lds + cur_slot * C::UNITB;
+                if constexpr (g == 0) nzw = (unsigned int)__builtin_amdgcn_readfirstlane((int)flag[gb & 1]);
+                const bool mfma_on = (((nzw >> g) & 1u) && !K1M_DBG(8)) || K1M_DBG(16);   // (bit4: MFMAs regardless)
+                if (mfma_on) {
+                    bv = Sbuf[(gb & 1) * 256 + g * 64 + lane];                            // B[k = lq][r = lr]
+                    const char *arow = unit + lq * C::ROWS + (wave * 16 + lr) * 4;       // A[i = lr][k = lq]
+#pragma unroll
+                    for (int tau = 0; tau < C::M; ++tau) av[tau] = *reinterpret_cast<const float *>(arow + tau * 1024);
+                }
+                // (the copy of the owner's tile for DIAG(nb): as it is BEFORE this block's rows go in)
+                if constexpr (g == 0) { if ((own_chain)) dump_tile(nb >> 4); }
+                if (mfma_on) run_mfmas();
+                // everything else AFTER the MFMAs are queued: the stream's bookkeeping (loader waves) and the owner's
+                // piece of DIAG(nb) run under the matrix pipe, not in front of it
+                if ((loader)) issue_unit();                             // into the slot the previous unit vacated
+                if ((own_next)) {                             // a quarter of DIAG(nb) per unit
+                    if constexpr (g == 0) { if (own_chain) { diag_begin(nb); diag_pre(gb, I0{}, I8{}); } }
+                    if constexpr (g == 1) { if (own_chain) diag_pre(gb, I8{}, I16{}); }
+                    if constexpr (g == 2) { if (own_chain) { diag_thresholds(nb); diag_steps(I0{}, I8{}); } }
+                    if constexpr (g == 3) { if (own_chain) diag_steps(I8{}, I16{}); diag_end(nb, np_force, gb + 1); }
+                }
                 if constexpr (g == 0) {
-                    nzw = (unsigned int)__builtin_amdgcn_readfirstlane((int)flag[gb & 1]);
                     if (nb_valid && !np_force) {
-                        if (wave == 15) issue_couplings(nb);
-                        if ((nb & 15) == 0) {
-                            // (opaque copy: LICM otherwise hoists the whole Philox block out of this branch and
-                            // runs it once per BLOCK in all 16 waves)
+                        if ((wave == 15)) issue_block(C::CB, nb, nb);
+                        if (((nb & 15) == 0)) {
+                            // (opaque copy: LICM otherwise hoists the whole Philox block out of this branch
+                            // and runs it once per BLOCK in all 16 waves)
                             int grp = nb >> 4;
                             asm volatile("" : "+s"(grp));
                             draw_thresholds(np_s, grp);
                         }
                     }
                 }
-                if constexpr (g == 3) {
-                    if (own_next) {
-#ifdef MI_K1M_TICKS
-                        unsigned long long keep = 0; K1M_TICK(keep); t_body[g] += keep;
-#endif
-                        diag(nb, np_force, gb + 1, unit);
-                        K1M_TICK(t_diag);
-                    }
-                }
-                if (((nzw >> g) & 1u) && !K1M_DBG(8)) {
-                    const float bv = Sbuf[(gb & 1) * 256 + g * 64 + lane];               // B[k = lq][r = lr]
-                    const char *arow = unit + lq * C::ROWS + (wave * 16 + lr) * 4;       // A[i = lr][k = lq]
-                    // all A operands first, then the MFMAs back to back (one read -> wait -> MFMA per tile is a
-                    // latency chain of 11 LDS round trips per unit and wave)
-                    float av[C::M];
-#pragma unroll
-                    for (int tau = 0; tau < C::M; ++tau) av[tau] = *reinterpret_cast<const float *>(arow + tau * 1024);
-#pragma unroll
-                    for (int tau = 0; tau < C::M; ++tau) asm volatile("" : "+v"(av[tau]));
-#pragma unroll
-                    for (int tau = 0; tau < C::M; ++tau) {
-                        // (n_pad - n < 256 columns = one tile per wave: only the last tile can be all padding)
-                        if (tau < C::M - 1 || last_tile_live)
-                            acc[tau] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tau], bv, acc[tau], 0, 0, 0);
-                    }
-                }
                 if constexpr (g == 2) {
-                    if (own_next && !np_force) dump_tile(nb >> 4);
+                    // E for the block after this one: rows of block nb x columns of ITS successor (the E of this
+                    // block is read in units 0 and 1: not before the rendezvous of unit 2)
+                    if ((nb_valid && wave == 15)) issue_block(C::EB, nb, nb + 1 == nbu ? 0 : nb + 1);
                 }
                 cur_slot = uni((cur_slot + 1 == C::U) ? 0 : cur_slot + 1);
                 processed = uni(processed + 1);
-                K1M_TICK(t_body[g]);
             });
             gb = uni(gb + 1);
         }
@@ -433,9 +479,10 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
         }
     }
 #ifdef MI_K1M_TICKS
-    if (lane == 0 && blockIdx.x == 0) {              // stats[4..7] / [8..11]: wave 1's wait / body time per unit phase
-        if (wave == 1) for (int g = 0; g < 4; ++g) { atomicAdd(&a.stats[4 + g], t_wait[g]); atomicAdd(&a.stats[8 + g], t_body[g]); }
-        atomicAdd(&a.stats[12], t_diag);              // all owners of workgroup 0
+    if (lane == 0 && blockIdx.x == 0 && wave == (a.debug >> 8)) {     // the wave picked by debug bits 8..11
+        for (int g = 0; g < 4; ++g) { atomicAdd(&a.stats[4 + g], t_wait[g]); atomicAdd(&a.stats[8 + g], t_body[g]); }
+        atomicAdd(&a.stats[12], t_thr);               // bookkeeping / loads after the rendezvous
+        atomicAdd(&a.stats[13], t_diag);              // its DIAG pieces
     }
 #endif
     if (lane == 0 && accepted) {

@@ -193,7 +193,7 @@ struct mi_sa_problem {
     unsigned int *d_pace = nullptr;          // kPaceWords per launch chunk
     int opt_pace = 1;                        // sweep pacing on/off (speed only)
     int opt_variant = 0;                     // 0 auto, 1 wave-per-replica (K1), 2 workgroup/LDS ring (K1w), 3 MFMA (K1m)
-    int opt_mfma_permille = 0;               // (K1m is not yet faster than K1w: scheduling is opt-in)
+    int opt_mfma_permille = 600;             // chunks that accept >= this share of their proposals hand the next one to K1m (0 = never)
 
     int opt_chunk_sweeps = 32;               // K1w/K1m: sweeps per launch of a chunked run (0 = one launch)
     float *d_fields = nullptr;               // cached fields between the launches of a chunked run
