@@ -289,6 +289,35 @@ def test_full_size_properties_pbmc3k_surrogate():
     assert np.array_equal(s2, o2) and i2["accepted"] == int(os2[1])
 
 
+def test_full_size_scheduled_dense_run_equals_the_workgroup_kernel_alone():
+    """BASELINE config 2 shape, a whole hot-to-cold schedule of 160 sweeps (5 chunks of 32): by default the hot chunks go to
+    K1m (fields as MFMA accumulators) and the rest to K1w; with `mfma_permille = 0` K1w serves all of them.  Same chain:
+    identical states, energies and acceptance counts -- and the kernel name says that both kernels ran."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(2638, 5, 15, 15, 9, seed=0)
+    m = models.build_bqm_qubo(graphs.EdgeListGraph(nodes, eu, ev, w), 0.05)
+    Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))
+    betas = models.make_beta_schedule(160, models.default_beta_range(m))
+    with Problem.dense(Qs) as p:
+        p.anneal(512, betas, 99, resync_interval=50)
+        name = p.kernel_name()
+        st, en, info = p.fetch()
+        p.set_option("mfma_permille", 0)
+        p.anneal(512, betas, 99, resync_interval=50)
+        name0 = p.kernel_name()
+        st0, en0, info0 = p.fetch()
+    assert "dense_mfma" in name and "dense_wg" in name and "dense_mfma" not in name0
+    assert np.array_equal(st, st0) and np.array_equal(en, en0)
+    assert info["accepted"] == info0["accepted"]
+    assert np.allclose(en, m.energies(st), rtol=E_RTOL_F64Q)
+    o2, _, os2 = so.sa_dense_philox(Qs, 2, betas[:40], 99, resync_interval=50)       # spot check against the oracle
+    with Problem.dense(Qs) as p:
+        p.set_option("chunk_sweeps", 8)
+        p.anneal(2, betas[:40], 99, resync_interval=50)                                # (R < 32: K1, one wave per replica)
+        s2, _, _ = p.fetch()
+    assert np.array_equal(s2, o2)
+
+
 @pytest.mark.parametrize("n,R,sweeps", [(4097, 3, 3), (9000, 2, 2), (17000, 2, 2)])
 def test_dense_beyond_4096_variables_workgroup_per_replica(n, R, sweeps):
     """K1x (one 512-thread workgroup per replica, fields spread over its registers, Q rows streamed from HBM)
