@@ -197,9 +197,8 @@ def clustering_bqm_3(G, iteration, dirs, solver, gamma_factor, color, terminate_
     bits (BQM_clustering.py:353-427; `add_linear_inequality_constraint` with lagrange = gamma)."""
     cut = build_bqm3_cut_qubo(G, k=8)                                 # :363-369
     n = cut.num_variables
-    from .models import _graph_total_weight, graph_arrays
-    _, _, _, w = graph_arrays(G)
-    gamma = gamma_factor * _graph_total_weight(G, w) / n              # :357-359
+    from .models import graph_arrays_and_weight
+    gamma = gamma_factor * graph_arrays_and_weight(G)[4] / n          # :357-359
     model = add_size_window_penalty(cut, lb=size_limit, ub=n / 6, lagrange_multiplier=gamma)  # :373-380
     kw = dict(max_iter=1, num_reads=1, qpu_reads=100, tabu_timeout=200,
               qpu_params={'label': 'Notebook - Hybrid Computing 1'})  # :386 (Kerberos arguments)

@@ -224,3 +224,28 @@ def test_synthetic_snn_shape():
     a = models.build_bqm_qubo(G, 0.05)
     b = models.build_bqm_qubo(Gn, 0.05)
     assert np.allclose(a.dense_Qs(), b.dense_Qs(), rtol=1e-13)
+
+
+def test_one_walk_graph_arrays_equal_the_networkx_calls_on_subgraph_views():
+    """`graph_arrays_and_weight` replaces the reference's three graph walks (number_of_edges, edges, size) by one.  On the
+    objects the recursive bisection passes down -- nested `G.subgraph(part)` views, whose node order may be the order
+    of the filter's node SET -- node list, edge order, weights and `size(weight=)` must come out bit-identical, self-loops
+    and weightless degree entries included; the model built from a view equals the one built from its copy."""
+    import networkx as nx
+    from scrna_seq_qannealing_clustering_amd.graphs import graph_from_edges, synthetic_snn
+    nodes, eu, ev, w, _ = synthetic_snn(700, 5, 15, 15, 4, seed=3)
+    G = graph_from_edges(nodes, eu, ev, w)
+    G.add_edge(nodes[5], nodes[5], weight=0.37)
+    G.add_edge(nodes[9], nodes[9], weight=1.25)
+    part = [v for i, v in enumerate(G.nodes) if (i * 7) % 3 != 0]
+    small = part[::5]                                             # < half of the nodes: the view iterates the SET
+    for H in (G, G.subgraph(part), G.subgraph(part).subgraph(part[::2]), G.subgraph(small), nx.Graph(G.subgraph(small))):
+        got = models.graph_arrays_and_weight(H)
+        want = models._graph_arrays_by_calls(H)
+        assert got[0] == want[0] == list(H.nodes)
+        assert all(np.array_equal(a, b) for a, b in zip(got[1:4], want[1:]))
+        assert got[4] == float(H.size(weight="weight"))
+        assert [(got[0][a], got[0][b]) for a, b in zip(got[1], got[2])] == [(u, v) for u, v in H.edges]
+    view, copy = G.subgraph(part), nx.Graph(G.subgraph(part))
+    mv, mc = models.build_bqm_qubo(view, 0.05), models.build_bqm_qubo(copy, 0.05)
+    assert mv.info["gamma"] == mc.info["gamma"] and np.array_equal(mv.lin, mc.lin) and np.array_equal(mv.val, mc.val)
