@@ -105,6 +105,18 @@ int mi_sa_debug_pace(mi_sa_problem *p, unsigned int *out, int words);
  * states back (scrna_seq_qannealing_clustering_amd/engine.py does).  Identity for n > 262144. */
 int mi_sa_plan_slot_order(const int32_t *rowptr, const int32_t *col, int n, int slot, int64_t *out_perm);
 
+/* The same planning with HOLES allowed: variable i gets the seat out_pos[i] = slot_index * slot + rank in a layout of
+ * *out_slots slots (>= ceil(n / slot), at most max_slots), the fewest -- tried from the packed count upwards -- for which
+ * the greedy pass leaves NO edge inside a slot; unused seats are holes.  Small or strongly clustered graphs (the
+ * subgraphs the reference's recursive bisection solves, its 256-node benchmark graphs) cannot be packed into
+ * ceil(n / 64) mutually non-adjacent blocks, and every block with an internal edge falls back to the serial accept
+ * loop: ten partly filled blocks run 3x faster than five full ones.  If max_slots does not suffice the packed layout
+ * is returned (*out_clashes = variables that share a slot with a neighbour, 0 otherwise; may be NULL).
+ * The caller builds the padded model: a hole is a variable without couplings whose linear term is +infinity --
+ * the structured kernels start such a variable at 0 and can never flip it (as the lanes past n). */
+int mi_sa_plan_slot_layout(const int32_t *rowptr, const int32_t *col, int n, int slot, int max_slots,
+                           int64_t *out_pos, int *out_slots, int *out_clashes);
+
 /* Diagnostic: copies the first `words` (<= 16) 64-bit statistics words of the last run ([0..2] as in
  * mi_sa_fetch; [8..12] per-phase cycle sums of builds compiled with -DMI_K2_PROFILE, otherwise 0). */
 int mi_sa_debug_stats(mi_sa_problem *p, uint64_t *out, int words);

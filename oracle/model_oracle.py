@@ -147,3 +147,56 @@ def slot_independent_order(rowptr, col, slot=64):
         where[v] = s
         fill[s] += 1
     return np.lexsort((np.arange(n), where)).astype(np.int64)
+
+
+def padded_slot_layout(rowptr, col, slot=64, max_slots=None):
+    """Restatement of mi_sa_plan_slot_layout: the greedy pass of ``slot_independent_order`` with ``nslots`` blocks of
+    ``slot`` seats each (no short last block), repeated with nslots = ceil(n / slot), then + max(1, nslots // 8) per
+    try, until no variable shares a block with a neighbour; beyond ``max_slots`` the packed result stands.  Returns
+    (pos, nslots, clashes): pos[i] = block * slot + rank of i inside its block (by original index)."""
+    import numpy as np
+    rowptr = np.asarray(rowptr)
+    col = np.asarray(col)
+    n = len(rowptr) - 1
+    s0 = (n + slot - 1) // slot
+    if max_slots is None:
+        max_slots = 3 * s0 + 4
+    max_slots = max(max_slots, s0)
+    order = np.argsort(-np.diff(rowptr), kind="stable")
+    big = np.int64(1) << 40
+
+    def greedy(nslots):
+        fill = np.zeros(nslots, dtype=np.int64)
+        where = np.full(n, -1, dtype=np.int64)
+        clashes = 0
+        for v in order:
+            key = fill * nslots + np.arange(nslots)
+            key = np.where(fill >= slot, 4 * big, key)
+            nb = where[col[rowptr[v]:rowptr[v + 1]]]
+            key[nb[nb >= 0]] += big
+            s = int(np.argmin(key))
+            clashes += int(key[s] >= big)
+            where[v] = s
+            fill[s] += 1
+        return where, clashes
+
+    nslots = s0
+    first = None
+    while True:
+        where, clashes = greedy(nslots)
+        if first is None:
+            first = (where, clashes)
+        if clashes == 0:
+            break
+        nxt = nslots + max(1, nslots // 8)
+        if nxt > max_slots:
+            where, clashes = first
+            nslots = s0
+            break
+        nslots = nxt
+    pos = np.empty(n, dtype=np.int64)
+    seat = np.zeros(nslots, dtype=np.int64)
+    for i in range(n):
+        pos[i] = where[i] * slot + seat[where[i]]
+        seat[where[i]] += 1
+    return pos, nslots, clashes

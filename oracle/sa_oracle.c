@@ -243,7 +243,10 @@ int orc_sa_dense_philox(const float *Qs, int n, double offset, int R, uint32_t r
  * Inside the slot, an accepted flip of i updates the g of its neighbours IN THE SAME SLOT (g_j += sgn*S_ij,
  * one fp32 add each, in flip order) and the integer s;  f_i = g_i + c * (float)(s - x_i)  (one fp32
  * multiply, one add).  No field survives a slot, so nothing drifts and there is nothing to re-synchronise
- * (resync_interval is accepted and ignored). */
+ * (resync_interval is accepted and ignored).
+ * A position whose linear term is +infinity is a HOLE (a seat of a padded sweep layout that holds no variable,
+ * include/mi_sa.h: mi_sa_plan_slot_layout): it is 0 from the start -- an explicit initial state included -- and
+ * takes no proposal; the random numbers stay addressed by position, so the holes only shift them. */
 #define ORC_SLOT 64
 int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val, const float *lin,
                             float c_pair, int n, double offset, int R, uint32_t replica_offset,
@@ -264,6 +267,7 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
         if (init) memcpy(x, init + (size_t)r * n, (size_t)n);
         else
             for (int i = 0; i < n; ++i) x[i] = (uint8_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) >> 31);
+        for (int i = 0; i < n; ++i) if (isinf(lin[i])) x[i] = 0;      /* a hole of a padded layout (see above) */
         for (int i = 0; i < n; ++i) S += x[i];
         for (int s = 0; s < num_sweeps; ++s) {
             float T = temps[betas_per_replica ? r : s];
@@ -276,6 +280,7 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
                     g[i - i0] = gi;
                 }
                 for (int i = i0; i < i1; ++i) {
+                    if (isinf(lin[i])) continue;                      /* hole: no variable sits here, nothing is proposed */
                     float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
                     float fi = g[i - i0] + c_pair * (float)(S - (int)x[i]);
                     float dE = x[i] ? -fi : fi;

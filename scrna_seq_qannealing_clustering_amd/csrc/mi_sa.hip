@@ -559,6 +559,77 @@ static int plan_slot_order_impl(const int32_t *rowptr, const int32_t *col, int n
     return MI_OK;
 }
 
+// One greedy pass with `nslots` slots of `slot` seats each (no short last slot: holes may sit anywhere).  Returns the
+// number of variables that had to share a slot with a neighbour; where[i] = slot of variable i.
+static int greedy_slots(const int32_t *rowptr, const int32_t *col, int n, int slot, int nslots,
+                        const std::vector<int> &order, std::vector<int> &where)
+{
+    std::vector<int> fill((size_t)nslots, 0), stamp((size_t)nslots, -1);
+    where.assign((size_t)n, -1);
+    int clashes = 0;
+    for (int v : order) {
+        for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+            const int w = where[(size_t)col[e]];
+            if (w >= 0) stamp[(size_t)w] = v;                // slot w holds a neighbour of v
+        }
+        int best = -1, best_nb = -1;
+        for (int s = 0; s < nslots; ++s) {
+            if (fill[(size_t)s] >= slot) continue;
+            if (stamp[(size_t)s] == v) { if (best_nb < 0 || fill[(size_t)s] < fill[(size_t)best_nb]) best_nb = s; }
+            else if (best < 0 || fill[(size_t)s] < fill[(size_t)best]) best = s;
+        }
+        const int s = best >= 0 ? best : best_nb;
+        if (best < 0) ++clashes;
+        where[(size_t)v] = s;
+        fill[(size_t)s]++;
+    }
+    return clashes;
+}
+
+static int plan_slot_layout_impl(const int32_t *rowptr, const int32_t *col, int n, int slot, int max_slots,
+                                 int64_t *pos, int *out_slots, int *out_clashes)
+{
+    const int s0 = (n + slot - 1) / slot;
+    if (max_slots < s0) max_slots = s0;
+    for (int i = 0; i < n; ++i) {
+        if (rowptr[i + 1] < rowptr[i]) return fail(MI_EINVAL, "rowptr is not monotone at %d", i);
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+            if (col[e] < 0 || col[e] >= n) return fail(MI_EINVAL, "bad column %d in row %d", col[e], i);
+    }
+    // variables by descending degree, ties by index (stable counting sort) -- as mi_sa_plan_slot_order
+    int maxdeg = 0;
+    for (int i = 0; i < n; ++i) maxdeg = std::max(maxdeg, rowptr[i + 1] - rowptr[i]);
+    std::vector<int> start((size_t)maxdeg + 2, 0), order((size_t)n);
+    for (int i = 0; i < n; ++i) start[(size_t)(maxdeg - (rowptr[i + 1] - rowptr[i])) + 1]++;
+    for (int d = 0; d <= maxdeg; ++d) start[(size_t)d + 1] += start[(size_t)d];
+    for (int i = 0; i < n; ++i) order[(size_t)start[(size_t)(maxdeg - (rowptr[i + 1] - rowptr[i]))]++] = i;
+    // fewest slots (from the fully packed count up, +1/8 per try) that leave no edge inside a slot; the packed
+    // layout's clashes stay if max_slots does not suffice
+    std::vector<int> where, first_where;
+    int nslots = s0, clashes = 0, first_clashes = 0;
+    for (;;) {
+        clashes = greedy_slots(rowptr, col, n, slot, nslots, order, where);
+        if (nslots == s0) { first_where = where; first_clashes = clashes; }
+        if (clashes == 0) break;
+        const int next = nslots + std::max(1, nslots / 8);
+        if (next > max_slots) { where = first_where; clashes = first_clashes; nslots = s0; break; }
+        nslots = next;
+    }
+    std::vector<int> seat((size_t)nslots, 0);
+    for (int i = 0; i < n; ++i) pos[i] = (int64_t)where[(size_t)i] * slot + seat[(size_t)where[(size_t)i]]++;   // by index inside a slot
+    *out_slots = nslots;
+    if (out_clashes) *out_clashes = clashes;
+    return MI_OK;
+}
+
+int mi_sa_plan_slot_layout(const int32_t *rowptr, const int32_t *col, int n, int slot, int max_slots,
+                           int64_t *out_pos, int *out_slots, int *out_clashes)
+{
+    if (!rowptr || !out_pos || !out_slots || (n > 0 && rowptr[n] > 0 && !col)) return fail(MI_EINVAL, "NULL argument");
+    if (n < 1 || slot < 1) return fail(MI_EINVAL, "n and slot must be >= 1");
+    return guarded([&]() -> int { return plan_slot_layout_impl(rowptr, col, n, slot, max_slots, out_pos, out_slots, out_clashes); });
+}
+
 int mi_sa_plan_slot_order(const int32_t *rowptr, const int32_t *col, int n, int slot, int64_t *out_perm)
 {
     if (!rowptr || !out_perm || (n > 0 && rowptr[n] > 0 && !col)) return fail(MI_EINVAL, "NULL argument");

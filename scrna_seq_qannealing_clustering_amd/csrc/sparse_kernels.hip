@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
     if (init) {
         for (int t = 0; t < slots; ++t) {
             const int i = t * 64 + lane;
-            const uint64_t m = __ballot(i < n && init[(size_t)r * n + i]);
+            const uint64_t m = __ballot(i < n && init[(size_t)r * n + i] && a.lin[i] < INFINITY);    // (a hole stays 0)
             if constexpr (XS == 2) reinterpret_cast<half_t *>(lds)[i] = (half_t)(float)((m >> lane) & 1ull);
             else if constexpr (XS == 1) lds[i] = (char)((m >> lane) & 1ull);
             else if (lane == 0) xm[t] = m;
@@ -91,7 +91,9 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
             for (int c = 0; c < 4; ++c) {
                 const int t = 4 * tg + c;
                 if (t >= slots) break;
-                const uint64_t m = __ballot(t * 64 + lane < n && (w[c] >> 31));
+                // (a variable whose linear term is +inf is a HOLE of a padded layout, mi_sa_plan_slot_layout: it
+                // starts at 0 and its dE = +inf is never accepted -- as the lanes past n)
+                const uint64_t m = __ballot(t * 64 + lane < n && (w[c] >> 31) && a.lin[t * 64 + lane] < INFINITY);
                 if constexpr (XS == 2) reinterpret_cast<half_t *>(lds)[t * 64 + lane] = (half_t)(float)((m >> lane) & 1ull);
                 else if constexpr (XS == 1) lds[t * 64 + lane] = (char)((m >> lane) & 1ull);
                 else if (lane == 0) xm[t] = m;

@@ -50,12 +50,13 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
             if (t >= slots) break;
             const int i = t * 64 + lane;
             bool xa, xb;
+            const bool real = i < n && a.lin[i] < INFINITY;         // (+inf linear term = hole of a padded layout: stays 0)
             if (init) {
-                xa = i < n && init[(size_t)rA * n + i] != 0;
-                xb = i < n && liveB && init[(size_t)rB * n + i] != 0;
+                xa = real && init[(size_t)rA * n + i] != 0;
+                xb = real && liveB && init[(size_t)rB * n + i] != 0;
             } else {
-                xa = i < n && (wa[c] >> 31);
-                xb = i < n && (wb[c] >> 31);
+                xa = real && (wa[c] >> 31);
+                xb = real && (wb[c] >> 31);
             }
             cell[i] = (xa ? 0x3c00u : 0u) | (xb ? 0x3c000000u : 0u);
             SA += __popcll(__ballot(xa));

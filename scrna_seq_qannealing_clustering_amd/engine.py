@@ -16,15 +16,20 @@ def _ptr(a, ctype):
 class Problem:
     """A model uploaded to one MI355X.  ``anneal`` is asynchronous; ``fetch``/``best`` wait."""
 
-    def __init__(self, handle, kind, n, num_cases, device, perm=None):
+    def __init__(self, handle, kind, n, num_cases, device, perm=None, seats=None, n_dev=None):
         self._h = handle
         self.kind = kind
-        self.n = n
+        self.n = n                       # variables of the CALLER's model
         self.num_cases = num_cases
         self.device = device
         self._last = None
-        self._inv = None
-        self.perm = perm                 # device variable j is the caller's variable perm[j] (None: identity)
+        self.perm = perm                 # device variable j is the caller's variable perm[j] (None: identity / padded)
+        # device column of the caller's variable i (None: identity), and the device-side variable count: larger than
+        # n under order="padded", where the seats no variable sits in are holes that stay 0
+        self._inv = None if perm is None else np.argsort(perm)
+        if seats is not None:
+            self._inv = np.asarray(seats, dtype=np.int64)
+        self.n_dev = int(n if n_dev is None else n_dev)
 
     # -- constructors ---------------------------------------------------------------------------
     @classmethod
@@ -48,6 +53,9 @@ class Problem:
         sweeps together are (as far as possible) mutually non-adjacent -- the kernel's integer fast path
         (models.slot_independent_order).  States go in and come out in the CALLER's order either way; the
         chain is a different (equally valid) sweep order, so results differ from ``order=None`` runs.
+        ``order="padded"``: the same with holes allowed -- as many blocks of 64 seats as it takes to keep EVERY edge
+        between blocks (models.padded_slot_layout); what small or strongly clustered graphs need (the subgraphs of the
+        reference's recursive bisection, its 256-node benchmark graphs), where no packed order is edge-free.
 
         ``energy_model=(val64, lin64, c_pair64)``: the caller's fp64 coefficients (same CSR structure); the
         reported energies are then evaluated on the device in that model (the chain itself runs in fp32)."""
@@ -62,8 +70,24 @@ class Problem:
                 val64, lin64 = permute_csr(rowptr, col, val64, perm)[2], lin64[perm]
             rowptr, col, val = permute_csr(rowptr, col, val, perm)
             lin = np.asarray(lin)[perm]
+        elif order == "padded":
+            # seats with holes (models.padded_slot_layout): the fewest blocks of 64 that keep every edge BETWEEN blocks.
+            # A hole is a variable without couplings whose linear term is +inf: the kernels start it at 0 and
+            # never flip it; its fp64 energy coefficients are 0.
+            from .models import pad_csr, padded_slot_layout
+            seats, nslots, _ = padded_slot_layout(rowptr, col)
+            n_caller, n_dev = len(lin), nslots * 64
+            if val64 is not None:
+                val64 = pad_csr(rowptr, col, val64, seats, n_dev)[2]
+                l64 = np.zeros(n_dev, dtype=np.float64)
+                l64[seats] = lin64
+                lin64 = l64
+            rowptr, col, val = pad_csr(rowptr, col, val, seats, n_dev)
+            lpad = np.full(n_dev, np.inf, dtype=np.float32)
+            lpad[seats] = np.asarray(lin, dtype=np.float32)
+            lin = lpad
         elif order is not None:
-            raise ValueError("order must be None or 'slots'")
+            raise ValueError("order must be None, 'slots' or 'padded'")
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         col = np.ascontiguousarray(col, dtype=np.int32)
         val = np.ascontiguousarray(val, dtype=np.float32)
@@ -74,7 +98,10 @@ class Problem:
         _lib.check(lib.mi_sa_problem_create_csr_rank1_f32(
             _ptr(rowptr, C.c_int32), _ptr(col, C.c_int32), _ptr(val, C.c_float),
             _ptr(lin, C.c_float), float(c_pair), n, float(offset), int(device), C.byref(h)))
-        prob = cls(h, _lib.KIND_CSR_RANK1, n, 2, device, perm=perm)
+        if order == "padded":
+            prob = cls(h, _lib.KIND_CSR_RANK1, n_caller, 2, device, seats=seats, n_dev=n_dev)
+        else:
+            prob = cls(h, _lib.KIND_CSR_RANK1, n, 2, device, perm=perm)
         if val64 is not None:
             prob._set_energy_model(val64, lin64, float(energy_model[2]), len(val))
         return prob
@@ -109,7 +136,7 @@ class Problem:
         return prob
 
     def _set_energy_model(self, val64, lin64, c_pair64, nnz):
-        if len(val64) != nnz or (lin64 is not None and len(lin64) != self.n):
+        if len(val64) != nnz or (lin64 is not None and len(lin64) != self.n_dev):
             self.close()
             raise ValueError("energy_model must have the structure of the fp32 model")
         val64 = np.ascontiguousarray(val64, dtype=np.float64)
@@ -180,8 +207,10 @@ class Problem:
             if init.shape != (num_reads, self.n):
                 raise ValueError("initial_states must have shape (num_reads, n) = (%d, %d)"
                                  % (num_reads, self.n))
-            if self.perm is not None:
-                init = np.take(init, self.perm, axis=1)
+            if self._inv is not None:
+                dev = np.zeros((num_reads, self.n_dev), dtype=self.state_dtype)
+                dev[:, self._inv] = init
+                init = dev
         _lib.check(_lib.load().mi_sa_anneal_ex(
             self._h, int(num_reads), C.c_uint32(int(replica_offset) & 0xFFFFFFFF), sweeps,
             _ptr(betas, C.c_double), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
@@ -237,7 +266,7 @@ class Problem:
         if self._last is None:
             raise RuntimeError("fetch() before anneal()")
         R = self._last[0]
-        st = np.empty((R, self.n), dtype=self.state_dtype) if states else None
+        st = np.empty((R, self.n_dev), dtype=self.state_dtype) if states else None
         en = np.empty(R, dtype=np.float64) if energies else None
         stats = np.zeros(3, dtype=np.uint64)
         _lib.check(_lib.load().mi_sa_fetch(
@@ -245,10 +274,8 @@ class Problem:
             _ptr(en, C.c_double), _ptr(stats, C.c_uint64)))
         info = {"proposals": int(R) * int(self._last[1]) * int(self.n),
                 "accepted": int(stats[1]), "row_bytes": int(stats[2])}
-        if st is not None and self.perm is not None:
+        if st is not None and self._inv is not None:
             # caller's variable i sits in device column inv[i]: a column gather (np.take is the fast form)
-            if self._inv is None:
-                self._inv = np.argsort(self.perm)
             st = np.take(st, self._inv, axis=1)
         return st, en, info
 
@@ -256,14 +283,12 @@ class Problem:
         idx = C.c_int(0)
         en = C.c_double(0.0)
         key = C.c_uint64(0)
-        st = np.empty(self.n, dtype=self.state_dtype) if want_state else None
+        st = np.empty(self.n_dev, dtype=self.state_dtype) if want_state else None
         _lib.check(_lib.load().mi_sa_best(
             self._h, C.byref(idx), C.byref(en), C.byref(key),
             st.ctypes.data_as(C.c_void_p) if st is not None else None))
-        if st is not None and self.perm is not None:
-            out = np.empty_like(st)
-            out[self.perm] = st
-            st = out
+        if st is not None and self._inv is not None:
+            st = st[self._inv]
         return int(idx.value), float(en.value), int(key.value), st
 
 

@@ -402,6 +402,41 @@ def slot_independent_order(rowptr: np.ndarray, col: np.ndarray, slot: int = 64) 
     return perm
 
 
+def padded_slot_layout(rowptr: np.ndarray, col: np.ndarray, slot: int = 64, max_slots: Optional[int] = None):
+    """``(pos, slots, clashes)``: seat ``pos[i] = slot_index * slot + rank`` of every variable in a layout of ``slots``
+    blocks of ``slot`` seats, the fewest (from ``ceil(n / slot)`` up to ``max_slots``, default ``3 * ceil(n / slot) + 4``)
+    for which the greedy colouring of ``slot_independent_order`` leaves NO edge inside a block; the seats left over
+    are holes.  ``clashes`` > 0: even ``max_slots`` did not suffice and the packed layout is returned.  Native
+    (``mi_sa_plan_slot_layout``); ``oracle/model_oracle.py`` keeps the restatement the tests compare it with."""
+    import ctypes as C
+    from . import _lib
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    n = len(rowptr) - 1
+    s0 = (n + slot - 1) // slot
+    if max_slots is None:
+        max_slots = 3 * s0 + 4
+    pos = np.empty(n, dtype=np.int64)
+    slots, clashes = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.load().mi_sa_plan_slot_layout(
+        rowptr.ctypes.data_as(C.POINTER(C.c_int32)), col.ctypes.data_as(C.POINTER(C.c_int32)), int(n), int(slot),
+        int(max_slots), pos.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(slots), C.byref(clashes)))
+    return pos, int(slots.value), int(clashes.value)
+
+
+def pad_csr(rowptr, col, val, pos, n_dev: int):
+    """CSR of the same symmetric matrix with variable ``i`` moved to seat ``pos[i]`` of ``n_dev`` seats; the other seats are
+    holes (empty rows).  Rows keep their neighbours in ascending NEW index order (as ``permute_csr``)."""
+    pos = np.asarray(pos, dtype=np.int64)
+    rows_old = np.repeat(np.arange(len(pos)), np.diff(rowptr))
+    r_new, c_new = pos[rows_old], pos[np.asarray(col)]
+    order = np.lexsort((c_new, r_new))
+    counts = np.bincount(r_new, minlength=n_dev)
+    rp = np.zeros(n_dev + 1, dtype=np.int32)
+    rp[1:] = np.cumsum(counts)
+    return rp, c_new[order].astype(np.int32), np.asarray(val)[order]
+
+
 def permute_csr(rowptr, col, val, perm):
     """CSR of the same symmetric matrix with variables renumbered by ``perm`` (``perm[new] = old``); rows keep
     their neighbours in ascending NEW index order."""

@@ -230,7 +230,7 @@ class MI355XSampler:
         if use_csr:
             prob = Problem.csr_rank1(model.rowptr, model.col, model.val.astype(np.float32),
                                      model.lin.astype(np.float32), float(np.float32(model.c_pair)),
-                                     offset=model.offset, device=self.device, order="slots",
+                                     offset=model.offset, device=self.device, order="padded",
                                      energy_model=(model.val, model.lin, model.c_pair))
         else:
             dense64 = model.dense_Qs()

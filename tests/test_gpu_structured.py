@@ -162,6 +162,59 @@ def test_csr_rank1_slot_independent_order_and_integer_fast_path():
         assert np.array_equal(s_best, st[idx])
 
 
+def test_csr_rank1_padded_layout_of_a_clustered_subgraph():
+    """order="padded": seats with holes, as many 64-blocks as it takes to keep every edge between blocks (what one planted
+    cluster -- a leaf of the reference's recursive bisection -- needs: no packed order of it is edge-free).  A hole is a
+    position with lin = +inf: it starts at 0, is never proposed, never flips.  The run equals the oracle on the SAME
+    padded model, for random and for given initial states, with one and with two replicas per wavefront; states,
+    energies (fp64 model) and the best state come back for the caller's n variables; proposals count n, not seats."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, lab = graphs.synthetic_snn(1500, 5, 15, 15, 6, seed=1)
+    idx = np.flatnonzero(lab == 0)
+    renum = -np.ones(1500, dtype=np.int64)
+    renum[idx] = np.arange(len(idx))
+    sel = np.isin(eu, idx) & np.isin(ev, idx)
+    m = models.build_bqm_qubo(graphs.EdgeListGraph([nodes[i] for i in idx], renum[eu[sel]].astype(np.int32),
+                                                   renum[ev[sel]].astype(np.int32), w[sel]), 0.05)
+    n = m.num_variables
+    c_pair = float(np.float32(m.c_pair))
+    pos, nslots, clashes = models.padded_slot_layout(m.rowptr, m.col)
+    assert clashes == 0 and nslots > (n + 63) // 64                            # the packed order would not do
+    N = nslots * 64
+    rp, cc, vv = models.pad_csr(m.rowptr, m.col, f32(m.val), pos, N)
+    lin = np.full(N, np.inf, dtype=np.float32)
+    lin[pos] = f32(m.lin)
+    betas = np.geomspace(2e-3, 40.0, 30)
+    init = np.random.RandomState(2).randint(0, 2, size=(9, n)).astype(np.uint8)
+    init_dev = np.zeros((9, N), dtype=np.uint8)
+    init_dev[:, pos] = init
+    o_rand = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, 9, betas, 8, replica_offset=3)
+    o_init = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, 9, betas, 8, init=init_dev)
+    holes = np.setdiff1d(np.arange(N), pos)
+    assert not o_rand[0][:, holes].any() and not o_init[0][:, holes].any()
+    with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), c_pair, order="padded",
+                           energy_model=(m.val, m.lin, m.c_pair)) as p:
+        assert p.n == n and p.n_dev == N
+        for mode in (2, 1):
+            p.set_option("k2_pair", mode)
+            p.anneal(9, betas, 8, replica_offset=3)
+            st, en, info = p.fetch()
+            assert ("pair" in p.kernel_name()) == (mode == 1)
+            assert st.shape == (9, n) and np.array_equal(st, o_rand[0][:, pos])
+            assert info["accepted"] == int(o_rand[2][1]) and info["proposals"] == 9 * 30 * n == int(o_rand[2][0])
+            assert np.allclose(en, m.energies(st), rtol=1e-12)
+            i_best, e_best, _, s_best = p.best()
+            assert np.array_equal(s_best, st[i_best]) and e_best == pytest.approx(en.min(), rel=1e-12)
+            p.anneal(9, betas, 8, initial_states=init)
+            st2, en2, info2 = p.fetch()
+            assert np.array_equal(st2, o_init[0][:, pos]) and info2["accepted"] == int(o_init[2][1])
+    # the sampler takes this layout for structured models: same energies as the model says, every replica a valid state
+    from scrna_seq_qannealing_clustering_amd import MI355XSampler
+    ss = MI355XSampler().sample_qubo(m, num_reads=64, num_sweeps=200, seed=5)
+    assert ss.record.sample.shape == (len(ss.record.energy), n)
+    assert np.allclose(ss.record.energy, m.energies(ss.record.sample.astype(np.uint8)), rtol=1e-12)
+
+
 def test_csr_rank1_two_replicas_per_wavefront():
     """K2p (csrc/sparse_pair_kernels.hip): two replicas share one wavefront and one set of adjacency registers.  Same
     chain as K2: equal to the oracle on the renumbered model and to the one-replica kernel, for an odd replica count

@@ -60,6 +60,41 @@ def test_native_slot_order_equals_its_restatement():
         models.slot_independent_order(np.arange(0, 131), np.r_[np.arange(1, 130), 500])
 
 
+def test_padded_slot_layout_keeps_every_edge_between_blocks():
+    """mi_sa_plan_slot_layout == its restatement; the layout of a strongly clustered graph (what a recursive bisection
+    leaves: here the planted clusters of the generator, one at a time and in pairs) needs more blocks than ceil(n / 64)
+    and then holds no edge inside a block; seats are unique; a complete graph falls back to the packed layout."""
+    nodes, eu, ev, w, lab = graphs.synthetic_snn(1500, 5, 15, 15, 6, seed=1)
+    padded_somewhere = False
+    for keep in ((0,), (1,), (2, 3), (0, 1, 2, 3, 4, 5)):
+        idx = np.flatnonzero(np.isin(lab, keep))
+        renum = -np.ones(1500, dtype=np.int64)
+        renum[idx] = np.arange(len(idx))
+        sel = np.isin(eu, idx) & np.isin(ev, idx)
+        rowptr, col, _ = models._csr_from_edges(len(idx), renum[eu[sel]].astype(np.int32), renum[ev[sel]].astype(np.int32), w[sel])
+        n = len(idx)
+        pos, nslots, clashes = models.padded_slot_layout(rowptr, col)
+        opos, onslots, oclashes = mo.padded_slot_layout(rowptr, col)
+        assert np.array_equal(pos, opos) and (nslots, clashes) == (onslots, oclashes)
+        assert clashes == 0 and nslots >= (n + 63) // 64 and len(set(pos.tolist())) == n and pos.max() < nslots * 64
+        rows = np.repeat(np.arange(n), np.diff(rowptr))
+        assert not np.any((pos[rows] >> 6) == (pos[col] >> 6))                       # no edge inside a block
+        assert np.bincount(pos >> 6, minlength=nslots).max() <= 64
+        padded_somewhere |= nslots > (n + 63) // 64
+        rp2, c2, v2 = models.pad_csr(rowptr, col, np.arange(len(col), dtype=np.float64), pos, nslots * 64)
+        assert rp2[-1] == len(col) and np.array_equal(np.diff(rp2)[pos], np.diff(rowptr))
+        assert all(np.all(np.diff(c2[rp2[i]:rp2[i + 1]]) > 0) for i in pos[::37])     # rows ascending
+    assert padded_somewhere
+    n = 70                                                          # complete graph: no number of blocks <= max helps
+    col = np.array([j for i in range(n) for j in range(n) if j != i])
+    rowptr = np.arange(0, n * (n - 1) + 1, n - 1)
+    pos, nslots, clashes = models.padded_slot_layout(rowptr, col, max_slots=8)
+    assert nslots == 2 and clashes > 0 and sorted(pos.tolist()) == sorted(set(pos.tolist()))
+    assert (np.array_equal(pos, mo.padded_slot_layout(rowptr, col, max_slots=8)[0]))
+    pos, nslots, clashes = models.padded_slot_layout(rowptr, col, max_slots=100)     # 70 blocks of one variable each
+    assert clashes == 0 and nslots >= 70
+
+
 def test_order_of_tiny_and_dense_graphs():
     assert models.slot_independent_order(np.array([0, 1, 2]), np.array([1, 0])).tolist() == [0, 1]
     n = 130                                                         # complete graph: conflicts are unavoidable
