@@ -117,6 +117,11 @@ int mi_sa_plan_slot_order(const int32_t *rowptr, const int32_t *col, int n, int 
 int mi_sa_plan_slot_layout(const int32_t *rowptr, const int32_t *col, int n, int slot, int max_slots,
                            int64_t *out_pos, int *out_slots, int *out_clashes);
 
+/* Potts (k-way) models: marks the holes of a padded layout -- absent[i] != 0: no variable sits at position i (it must
+ * have no couplings).  Such a position keeps label 0, belongs to no cluster (it is not counted in the cluster sizes
+ * of the penalty term), takes no proposal.  Call before the first anneal of the problem. */
+int mi_sa_problem_set_absent(mi_sa_problem *p, const uint8_t *absent);
+
 /* Diagnostic: copies the first `words` (<= 16) 64-bit statistics words of the last run ([0..2] as in
  * mi_sa_fetch; [8..12] per-phase cycle sums of builds compiled with -DMI_K2_PROFILE, otherwise 0). */
 int mi_sa_debug_stats(mi_sa_problem *p, uint64_t *out, int words);

@@ -393,11 +393,13 @@ int orc_csr_rank1_fp32_vs_fp64_decisions(const int *rowptr, const int *col, cons
  * (the "cluster_size >= 20" constraints of CQM_clustering.py:46-48 as a hard constraint): a move out of a
  * cluster that holds exactly min_size variables is rejected whatever its dE.  The restricted chain still
  * satisfies detailed balance on the feasible set; the initial state must be feasible. */
-int orc_potts_csr_philox_min(const int *rowptr, const int *col, const float *val, float c_pair, int n,
-                             int K, double lin_offset, int R, uint32_t replica_offset, int num_sweeps,
-                             const double *betas, uint64_t seed, const uint16_t *init,
-                             uint16_t *out_labels, double *out_energy, uint64_t *out_stats,
-                             uint32_t sweep_offset, int betas_per_replica, int min_size)
+/* absent (nullable): absent[i] != 0 -- position i is a HOLE of a padded sweep layout (include/mi_sa.h:
+ * mi_sa_problem_set_absent): label 0, in no cluster, no proposal; random numbers stay addressed by position. */
+int orc_potts_csr_philox_absent(const int *rowptr, const int *col, const float *val, float c_pair, int n,
+                                int K, double lin_offset, int R, uint32_t replica_offset, int num_sweeps,
+                                const double *betas, uint64_t seed, const uint16_t *init,
+                                uint16_t *out_labels, double *out_energy, uint64_t *out_stats,
+                                uint32_t sweep_offset, int betas_per_replica, int min_size, const uint8_t *absent)
 {
     uint64_t tot_prop = 0, tot_acc = 0;
     const int nb = betas_per_replica ? R : num_sweeps;
@@ -412,10 +414,14 @@ int orc_potts_csr_philox_min(const int *rowptr, const int *col, const float *val
         else
             for (int i = 0; i < n; ++i)
                 l[i] = (uint16_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) % (uint32_t)K);
-        for (int i = 0; i < n; ++i) cnt[l[i]]++;
+        for (int i = 0; i < n; ++i) {
+            if (absent && absent[i]) l[i] = 0;
+            else cnt[l[i]]++;
+        }
         for (int s = 0; s < num_sweeps; ++s) {
             float T = temps[betas_per_replica ? r : s];
             for (int i = 0; i < n && K > 1; ++i) {
+                if (absent && absent[i]) continue;
                 int a = l[i];
                 int b = (a + 1 + (int)(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 2) % (uint32_t)(K - 1))) % K;
                 float ha = 0.0f, hb = 0.0f;
@@ -449,6 +455,17 @@ int orc_potts_csr_philox_min(const int *rowptr, const int *col, const float *val
     free(temps);
     if (out_stats) { out_stats[0] += tot_prop; out_stats[1] += tot_acc; }
     return 0;
+}
+
+int orc_potts_csr_philox_min(const int *rowptr, const int *col, const float *val, float c_pair, int n,
+                             int K, double lin_offset, int R, uint32_t replica_offset, int num_sweeps,
+                             const double *betas, uint64_t seed, const uint16_t *init,
+                             uint16_t *out_labels, double *out_energy, uint64_t *out_stats,
+                             uint32_t sweep_offset, int betas_per_replica, int min_size)
+{
+    return orc_potts_csr_philox_absent(rowptr, col, val, c_pair, n, K, lin_offset, R, replica_offset, num_sweeps, betas,
+                                       seed, init, out_labels, out_energy, out_stats, sweep_offset, betas_per_replica,
+                                       min_size, NULL);
 }
 
 int orc_potts_csr_philox(const int *rowptr, const int *col, const float *val, float c_pair, int n,

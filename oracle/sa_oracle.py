@@ -93,7 +93,7 @@ def sa_csr_rank1_philox(rowptr, col, val, lin, c_pair, R, betas, seed, offset=0.
 
 
 def potts_csr_philox(rowptr, col, val, c_pair, n, K, R, betas, seed, lin_offset=0.0,
-                     replica_offset=0, init=None, sweep_offset=0, num_sweeps=None, min_size=0):
+                     replica_offset=0, init=None, sweep_offset=0, num_sweeps=None, min_size=0, absent=None):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     col = np.ascontiguousarray(col, dtype=np.int32)
     val = np.ascontiguousarray(val, dtype=np.float32)
@@ -103,12 +103,15 @@ def potts_csr_philox(rowptr, col, val, c_pair, n, K, R, betas, seed, lin_offset=
     stats = np.zeros(2, dtype=np.uint64)
     if init is not None:
         init = np.ascontiguousarray(init, dtype=np.uint16)
-    rc = lib().orc_potts_csr_philox_min(
+    if absent is not None:
+        absent = np.ascontiguousarray(absent, dtype=np.uint8)
+    rc = lib().orc_potts_csr_philox_absent(
         _p(rowptr, C.c_int), _p(col, C.c_int), _p(val, C.c_float), C.c_float(c_pair), C.c_int(n),
         C.c_int(K), C.c_double(lin_offset), C.c_int(R), C.c_uint32(replica_offset),
         C.c_int(len(betas) if num_sweeps is None else num_sweeps), _p(betas, C.c_double), C.c_uint64(seed),
         _p(init, C.c_uint16), _p(labels, C.c_uint16), _p(energy, C.c_double), _p(stats, C.c_uint64),
-        C.c_uint32(sweep_offset), C.c_int(0 if num_sweeps is None else 1), C.c_int(int(min_size)))
+        C.c_uint32(sweep_offset), C.c_int(0 if num_sweeps is None else 1), C.c_int(int(min_size)),
+        _p(absent, C.c_uint8))
     assert rc == 0
     return labels, energy, stats
 

@@ -174,7 +174,8 @@ struct mi_sa_problem {
     double c_pair64 = 0.0;
     std::vector<int32_t> h_rowptr;           // structured kinds: the CSR row pointers given at creation
     uint2 *d_rows = nullptr;                 // K2: row-major adjacency, in-slot neighbours first
-    uint32_t *d_meta = nullptr;              // K2: in-slot count | degree << 8
+    uint32_t *d_meta = nullptr;              // K2 / K3: in-slot count | degree << 8 | absent << 31
+    std::vector<uint32_t> h_meta;            // host copy (mi_sa_problem_set_absent)
     uint4 *d_adj4 = nullptr;                 // K2: packed slot adjacency (see EllArgs::adj4)
     uint4 *d_adj4p = nullptr;                // K2p (two replicas per wavefront): the same with neighbour word = 4 * index; null = not eligible
     uint32_t *d_slot_flags = nullptr;        // K2: slots with internal edges
@@ -448,7 +449,7 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
         for (int i = 0; i < slots * 64; ++i) {
             uint2 *row = hr.data() + (size_t)i * D;
             for (int k = 0; k < D; ++k) row[k] = make_uint2((uint32_t)(i < n ? i : 0), 0u);   // (self, +0.0f)
-            if (i >= n) continue;
+            if (i >= n) { hm[i] = 0x80000000u; continue; }    // bit 31: no variable at this position (K3 reads it)
             int k = 0, nin = 0;
             for (int pass = 0; pass < 2; ++pass)
                 for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
@@ -465,6 +466,7 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
         HIP_TRY(hipMalloc((void **)&p->d_meta, hm.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(p->d_rows, hr.data(), hr.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_meta, hm.data(), hm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        p->h_meta = hm;
         if (p->kind == MI_KIND_CSR_RANK1) {
             // K2's register image of a slot: groups of four (neighbour, value) per lane, the neighbour already
             // translated into where its state bit lives in LDS (the state masks start at LDS address 0)
@@ -706,6 +708,24 @@ static int set_energy_model_impl(mi_sa_problem *p, const double *val, const doub
     HIP_TRY(hipMemcpy(p->d_lin64, hl.data(), hl.size() * sizeof(double), hipMemcpyHostToDevice));
     p->c_pair64 = c_pair;
     return MI_OK;
+}
+
+int mi_sa_problem_set_absent(mi_sa_problem *p, const uint8_t *absent)
+{
+    if (!p || !absent) return fail(MI_EINVAL, "NULL argument");
+    if (p->kind != MI_KIND_POTTS_CSR)
+        return fail(MI_EUNSUPPORTED, "holes of a Potts model only (a binary CSR model marks them by lin = +inf)");
+    return guarded([&]() -> int {
+        for (int i = 0; i < p->n; ++i) {
+            if (absent[i] && (p->h_meta[(size_t)i] & 0x00ffff00u))
+                return fail(MI_EINVAL, "variable %d is marked absent but has couplings", i);
+            p->h_meta[(size_t)i] = (p->h_meta[(size_t)i] & 0x7fffffffu) | (absent[i] ? 0x80000000u : 0u);
+        }
+        HIP_TRY(hipSetDevice(p->device));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemcpy(p->d_meta, p->h_meta.data(), p->h_meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return MI_OK;
+    });
 }
 
 int mi_sa_problem_set_energy_model_f64(mi_sa_problem *p, const double *val, const double *lin, double c_pair)

@@ -412,7 +412,10 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             if (t >= slots) break;
             const int i = t * 64 + lane;
             uint32_t v = 0;
-            if (i < n) v = init ? (uint32_t)init[(size_t)r * n + i] : (w[c] % (uint32_t)K);
+            // (bit 31 of meta: no variable sits at this position -- past n, or a hole of a padded layout,
+            // mi_sa_plan_slot_layout / mi_sa_problem_set_absent: label 0, in no cluster, never proposed)
+            const bool present = (a.meta[i] >> 31) == 0u;
+            if (present) v = init ? (uint32_t)init[(size_t)r * n + i] : (w[c] % (uint32_t)K);
             lab[i] = (uint8_t)v;
         }
     }
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
     for (int q = 0; q < K; ++q) {
         int c = 0;
         for (int t = 0; t < slots; ++t)
-            c += __popcll(__ballot(t * 64 + lane < n && lab[t * 64 + lane] == q));
+            c += __popcll(__ballot((a.meta[t * 64 + lane] >> 31) == 0u && lab[t * 64 + lane] == q));
         if (lane == q) cntv = c;
     }
     cnt[lane] = cntv;
@@ -483,7 +486,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
             if constexpr (PF) nxt = fetch_adj(t + 1);
             K2_TICK(t_init);
             float thr = neglog_u(w0c) * T;
-            if (i >= n) thr = -INFINITY;
+            if (metav >> 31) thr = -INFINITY;                // nobody sits here
             const int la = lab[i];
             uint32_t rem = w2c - __umulhi(w2c, magic) * dK;  // in [0, 2 dK)
             rem = rem >= dK ? rem - dK : rem;

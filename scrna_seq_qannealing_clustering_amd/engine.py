@@ -110,7 +110,7 @@ class Problem:
     def potts_csr(cls, rowptr, col, val, c_pair: float, n: int, num_cases: int,
                   lin_offset: float = 0.0, device: int = 0, order: Optional[str] = None,
                   energy_model=None) -> "Problem":
-        """``order="slots"``: as in :meth:`csr_rank1` (labels go in and come out in the caller's order).
+        """``order="slots"`` / ``"padded"``: as in :meth:`csr_rank1` (labels go in and come out in the caller's order).
         ``energy_model=(val64, c_pair64)``: fp64 coefficients for the reported energies."""
         perm = None
         val64 = None if energy_model is None else np.asarray(energy_model[0], dtype=np.float64)
@@ -120,8 +120,17 @@ class Problem:
             if val64 is not None:
                 val64 = permute_csr(rowptr, col, val64, perm)[2]
             rowptr, col, val = permute_csr(rowptr, col, val, perm)
+        elif order == "padded":
+            # seats with holes, as in csr_rank1; a hole of a Potts model is marked through mi_sa_problem_set_absent:
+            # label 0, in no cluster, never proposed
+            from .models import pad_csr, padded_slot_layout
+            seats, nslots, _ = padded_slot_layout(rowptr, col)
+            n_caller, n = int(n), nslots * 64
+            if val64 is not None:
+                val64 = pad_csr(rowptr, col, val64, seats, n)[2]
+            rowptr, col, val = pad_csr(rowptr, col, val, seats, n)
         elif order is not None:
-            raise ValueError("order must be None or 'slots'")
+            raise ValueError("order must be None, 'slots' or 'padded'")
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         col = np.ascontiguousarray(col, dtype=np.int32)
         val = np.ascontiguousarray(val, dtype=np.float32)
@@ -130,7 +139,16 @@ class Problem:
         _lib.check(lib.mi_sa_problem_create_potts_csr_f32(
             _ptr(rowptr, C.c_int32), _ptr(col, C.c_int32), _ptr(val, C.c_float), float(c_pair),
             int(n), int(num_cases), float(lin_offset), int(device), C.byref(h)))
-        prob = cls(h, _lib.KIND_POTTS_CSR, int(n), int(num_cases), device, perm=perm)
+        if order == "padded":
+            prob = cls(h, _lib.KIND_POTTS_CSR, n_caller, int(num_cases), device, seats=seats, n_dev=n)
+            absent = np.ones(n, dtype=np.uint8)
+            absent[seats] = 0
+            rc = lib.mi_sa_problem_set_absent(h, absent.ctypes.data_as(C.POINTER(C.c_uint8)))
+            if rc:
+                prob.close()
+                _lib.check(rc)
+        else:
+            prob = cls(h, _lib.KIND_POTTS_CSR, int(n), int(num_cases), device, perm=perm)
         if val64 is not None:
             prob._set_energy_model(val64, None, float(energy_model[1]), len(val))
         return prob

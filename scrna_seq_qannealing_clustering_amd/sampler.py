@@ -283,7 +283,7 @@ class MI355XSampler:
         betas, beta_range, stype = self._schedule(kw, lambda: default_potts_beta_range(model))
         prob = Problem.potts_csr(model.rowptr, model.col, model.val.astype(np.float32),
                                  float(np.float32(model.c_pair)), n, model.num_cases,
-                                 lin_offset=model.lin_offset, device=self.device, order="slots",
+                                 lin_offset=model.lin_offset, device=self.device, order="padded",
                                  energy_model=(model.val, model.c_pair))
         # the CQM's "every cluster has at least m members" (CQM_clustering.py:46-48): a hard constraint on moves
         min_size = int(kw.get("min_cluster_size", model.info.get("min_cluster_size", 0)) or 0)

@@ -215,6 +215,58 @@ def test_csr_rank1_padded_layout_of_a_clustered_subgraph():
     assert np.allclose(ss.record.energy, m.energies(ss.record.sample.astype(np.uint8)), rtol=1e-12)
 
 
+def test_potts_padded_layout_of_a_clustered_subgraph():
+    """K3 under order="padded": the holes (mi_sa_problem_set_absent) keep label 0, sit in no cluster -- the size penalty
+    does not see them -- and are never proposed.  Equal to the oracle on the same padded model with the same positions
+    absent: random and given initial labels, K = 4 (fixed-point rounds) and K = 20 (serial moves), the minimum-size
+    constraint; labels and fp64 energies come back for the caller's n variables."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, lab = graphs.synthetic_snn(1500, 5, 15, 15, 6, seed=1)
+    idx = np.flatnonzero(lab == 0)
+    renum = -np.ones(1500, dtype=np.int64)
+    renum[idx] = np.arange(len(idx))
+    sel = np.isin(eu, idx) & np.isin(ev, idx)
+    G = graphs.EdgeListGraph([nodes[i] for i in idx], renum[eu[sel]].astype(np.int32), renum[ev[sel]].astype(np.int32), w[sel])
+    for K, min_size in ((4, 0), (20, 0), (4, 30)):
+        pm = models.build_dqm_potts(G, K, 0.005)
+        n = pm.num_variables
+        c_pair = float(np.float32(pm.c_pair))
+        pos, nslots, clashes = models.padded_slot_layout(pm.rowptr, pm.col)
+        assert clashes == 0 and nslots > (n + 63) // 64
+        N = nslots * 64
+        rp, cc, vv = models.pad_csr(pm.rowptr, pm.col, f32(pm.val), pos, N)
+        absent = np.ones(N, dtype=np.uint8)
+        absent[pos] = 0
+        betas = np.geomspace(0.05, 60.0, 25)
+        init = (np.arange(9 * n).reshape(9, n) % K).astype(np.uint16)           # every cluster well above min_size
+        init_dev = np.zeros((9, N), dtype=np.uint16)
+        init_dev[:, pos] = init
+        o_init = so.potts_csr_philox(rp, cc, vv, c_pair, N, K, 9, betas, 8, lin_offset=pm.lin_offset, init=init_dev,
+                                     min_size=min_size, absent=absent)
+        with Problem.potts_csr(pm.rowptr, pm.col, f32(pm.val), c_pair, n, K, lin_offset=pm.lin_offset, order="padded",
+                               energy_model=(pm.val, pm.c_pair)) as p:
+            assert p.n == n and p.n_dev == N
+            if min_size:
+                p.set_option("min_cluster_size", min_size)
+            p.anneal(9, betas, 8, initial_states=init)
+            st, en, info = p.fetch()
+            assert st.shape == (9, n) and np.array_equal(st, o_init[0][:, pos])
+            assert info["accepted"] == int(o_init[2][1]) and info["proposals"] == 9 * 25 * n == int(o_init[2][0])
+            assert np.allclose(en, pm.energies(st), rtol=1e-12)
+            if min_size:
+                assert min(np.bincount(row, minlength=K).min() for row in st) >= min_size
+            else:
+                o_rand = so.potts_csr_philox(rp, cc, vv, c_pair, N, K, 9, betas, 8, lin_offset=pm.lin_offset,
+                                             replica_offset=3, absent=absent)
+                p.anneal(9, betas, 8, replica_offset=3)
+                st2, en2, info2 = p.fetch()
+                assert np.array_equal(st2, o_rand[0][:, pos]) and info2["accepted"] == int(o_rand[2][1])
+                assert not o_rand[0][:, np.flatnonzero(absent)].any()
+    from scrna_seq_qannealing_clustering_amd import MI355XSampler
+    ss = MI355XSampler().sample_dqm(models.build_dqm_potts(G, 4, 0.005), num_reads=64, num_sweeps=200, seed=5)
+    assert ss.record.sample.shape[1] == len(idx)
+
+
 def test_csr_rank1_two_replicas_per_wavefront():
     """K2p (csrc/sparse_pair_kernels.hip): two replicas share one wavefront and one set of adjacency registers.  Same
     chain as K2: equal to the oracle on the renumbered model and to the one-replica kernel, for an odd replica count
