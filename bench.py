@@ -243,7 +243,7 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
     return out
 
 
-def dense_xl_50k(rank_device, n=50000, replicas=128, sweeps=8):
+def dense_xl_50k(rank_device, n=50000, replicas=256, sweeps=4):
     """BASELINE config 4 in its literal form -- the one kernel of the path that really streams Q from HBM: a
     synthetic 50 000-cell SNN graph built on the GPU (snn.build_snn), the clustering_bqm QUBO as a dense fp32
     matrix (10.6 GB resident in HBM), K1x (one workgroup per replica; an ACCEPTED flip streams one padded row of

@@ -6,7 +6,7 @@ tag=${1:-pmc_dense50k}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/f -- python $GRAFT_REPO_ROOT/scripts/run_dense50k.py --replicas 128 --sweeps 8 --start 0 > $out/run.json 2> $out/run.err || echo "failed rc=$?" >> $out/status.txt
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/f -- python $GRAFT_REPO_ROOT/scripts/run_dense50k.py --replicas 256 --sweeps 4 --start 0 > $out/run.json 2> $out/run.err || echo "failed rc=$?" >> $out/status.txt
 for f in $(find $out/f -name '*counter_collection.csv'); do head -1 $f > $out/FETCH_SIZE.csv; grep dense_xl $f >> $out/FETCH_SIZE.csv; done
 rm -rf $out/f
 python - <<PY
@@ -15,7 +15,7 @@ d = json.loads([l for l in open("$out/run.json") if l.startswith("{")][-1])
 kib = sum(float(r["Counter_Value"]) for r in csv.DictReader(open("$out/FETCH_SIZE.csv")))
 d["pmc"] = {"FETCH_SIZE_KiB": kib, "fabric_read_bytes_x2": kib * 1024 * 2}
 d["fabric_read_GBps"] = kib * 1024 * 2 / (d["kernel_ms"] * 1e-3) / 1e9
-d["method"] = "rocprofv3 --pmc FETCH_SIZE on scripts/run_dense50k.py --replicas 128 --sweeps 8 --start 0; x2 per the gfx950 half-count note (MI355X_MICROARCH.md, HBM); kernel_ms of the profiled run"
+d["method"] = "rocprofv3 --pmc FETCH_SIZE on scripts/run_dense50k.py --replicas 256 --sweeps 4 --start 0; x2 per the gfx950 half-count note (MI355X_MICROARCH.md, HBM); kernel_ms of the profiled run"
 json.dump(d, open("$out/r02_dense50k.json", "w"), indent=1)
 print(json.dumps(d))
 PY
