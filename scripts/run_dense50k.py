@@ -40,10 +40,11 @@ with Problem.dense(Qs) as p:
     t_upload = time.perf_counter() - t0
     p.anneal(a.replicas, betas, 1234)
     ms = p.kernel_ms()
+    p_kernel_name = p.kernel_name()
     st, en, info = p.fetch()
 n_pad = ((n + 4095) // 4096) * 4096
 init_rows = int(st.shape[0] * n / 2)                       # field initialisation streams ~n/2 rows per replica
-out = {"kernel": "k_anneal_dense_xl<%d>" % (n_pad // 4096), "n": n, "replicas": a.replicas, "sweeps": a.sweeps,
+out = {"kernel": p_kernel_name, "n": n, "replicas": a.replicas, "sweeps": a.sweeps,
        "kernel_ms": ms, "updates_per_s": a.replicas * a.sweeps * n / (ms * 1e-3),
        "acceptance": info["accepted"] / info["proposals"],
        "rows_streamed": info["accepted"] + init_rows,

@@ -1,0 +1,310 @@
+// dense_xg_kernels.hip -- K1g: the dense-QUBO chain for LARGE models (4096 < n <= 65536) and MANY replicas, with the
+// row updates of all replicas as one GEMM-shaped pass per block of rows on the matrix cores (gfx950).
+//
+// Same chain as K1 / K1w / K1m / K1x, bit for bit (oracle 2a).  K1x gives a replica a workgroup
+// and streams one 4 n-byte row of Q per accepted flip through it: at n = 50 000 that is 213 KB behind a barrier and a
+// full L2 round trip per flip (7.7 us), and every replica fetches every row for itself.  Here all R replicas walk
+// the rows TOGETHER, 64 rows (one "block") at a time, with the cached fields of all replicas in HBM / Infinity
+// Cache as F[column][replica]:
+//   DIAG(b)   one thread per replica: the 64 decisions of block b in sequence, on the replica's 64 fields of the
+//             block's own columns and the 64 x 64 coupling block Q2[b][b] (LDS, broadcast reads) -- leaves the signs
+//             S[k][r] in {-1, 0, +1} (0 = rejected), the new state bits, and a "some replica flipped" flag per
+//             64 replicas;
+//   PANEL(b)  F[:, r] += sum_k Q2[64 b + k][:] * S[k][r]  for ALL columns and replicas: tiles of
+//             v_mfma_f32_16x16x4_f32 chained over the 64 rows.  The f32-input MFMA is an exact fp32 fmaf chain in
+//             k order, D = fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C)))), i.e. the oracle's "f += sgn * Q2[row]"
+//             for the accepted rows in row order (K1m relies on the same identity); a rejected row contributes
+//             fma(q, 0, f) = f.  The block's own columns are updated by the same pass, so DIAG's private copies
+//             are simply dropped.
+// A Q row is read once per sweep for all replicas (10.6 GB per sweep at n = 50 000 instead of 213 KB per accepted
+// flip and replica); what the pass costs is the read-modify-write of F (n_pad x R x 8 B per block) and
+// 2 * 64 * n_pad * R flop per block on the matrix pipe.  Two launches per block (stream order is the chain's
+// order); thresholds for four blocks at a time (one Philox block serves four 64-variable slots).
+// Used for R >= 256 replicas; K1x keeps the small batches.
+#include "mi_sa_device.h"
+
+namespace mi_sa_impl {
+namespace {
+
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+
+constexpr int kXgB = 64;                 // rows per block = variables per slot of the RNG addressing
+constexpr int kXgCols = 256;             // columns per PANEL workgroup (4 waves x 64)
+constexpr int kXgReps = 64;              // replicas per PANEL workgroup (= one flag word, one DIAG wavefront)
+
+struct XgArgs {
+    const float *Q2;        // n rows x stride floats (zero diagonal, zero padding)
+    const float *diag;      // stride floats
+    size_t stride;          // floats per row of Q2
+    float *F;               // cached fields, [Rp / 64][ncols][64]: the 64 replicas of a PANEL workgroup contiguous per
+                            // column, so that its 256 x 64 tile is ONE 64 KB run of memory (see fidx)
+    unsigned long long *XT; // [nblocks][Rp] state bits of a block, bit k = x of variable 64 b + k
+    float *S;               // [64][Rp] signs of the current block
+    float *TH;              // [4][64][Rp] thresholds of four consecutive blocks
+    unsigned int *flags;    // [2][Rp / 64]
+    const float *temps;
+    const uint8_t *init;    // nullable, R x n
+    uint8_t *states;        // R x n
+    double *energy;
+    unsigned long long *stats;
+    double offset;
+    int n, R, Rp, ncols, nblocks;
+    uint32_t replica_offset, seed_lo, seed_hi;
+    int temps_per_replica;
+};
+
+__device__ __forceinline__ size_t fidx(const XgArgs &a, int col, int r)
+{
+    return ((size_t)(r >> 6) * a.ncols + col) * 64 + (r & 63);
+}
+
+// ---- state bits: XT[b][r] from the given initial states or the chain's own random start (tag 1) ----
+__global__ void __launch_bounds__(64) k_xg_init_state(XgArgs a)
+{
+    const int lane = threadIdx.x, r = blockIdx.x, tg = blockIdx.y;       // one wavefront per (replica, four blocks)
+    const uint32_t g = a.replica_offset + (uint32_t)r;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (!a.init) philox4x32_10((uint32_t)(tg * 64 + lane), 0u, g, 1u, a.seed_lo, a.seed_hi, w);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int b = 4 * tg + c, i = b * 64 + lane;
+        if (b >= a.nblocks) break;
+        bool bit = false;
+        if (i < a.n) bit = a.init ? (a.init[(size_t)r * a.n + i] != 0) : ((w[c] >> 31) != 0);
+        const unsigned long long m = __ballot(bit);
+        if (lane == 0) a.XT[(size_t)b * a.Rp + r] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_xg_fill_fields(XgArgs a)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;           // over ncols * Rp
+    if (idx < (size_t)a.ncols * a.Rp) a.F[idx] = a.diag[(idx >> 6) % (size_t)a.ncols];
+}
+
+// thresholds of blocks 4 tg .. 4 tg + 3 for sweep s: TH[c][lane][r] = -ln(u) * T   (-inf: no such variable / replica)
+__global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_t sweep, int s_local)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x, lane = blockIdx.y;
+    if (r >= a.Rp) return;
+    float th[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (r < a.R) {
+        const float T = a.temps[a.temps_per_replica ? r : s_local];
+        uint32_t w[4];
+        philox4x32_10((uint32_t)(tg * 64 + lane), sweep, a.replica_offset + (uint32_t)r, 0u, a.seed_lo, a.seed_hi, w);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if ((4 * tg + c) * 64 + lane < a.n) th[c] = neglog_u(w[c]) * T;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a.TH[((size_t)c * 64 + lane) * a.Rp + r] = th[c];
+}
+
+// ---- DIAG(b): one thread per replica ----
+__global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force)
+{
+    __shared__ __attribute__((aligned(16))) float C[kXgB][kXgB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = blockIdx.x * 256 + tid;
+    const int R0 = b * kXgB;
+    if (!force) {
+        // coupling block: row R0 + k (zero past n), columns R0 .. R0 + 63
+        for (int e = tid; e < kXgB * kXgB / 4; e += 256) {
+            const int k = e >> 4, j4 = (e & 15) * 4;
+            f32x4acc q = {0, 0, 0, 0};
+            if (R0 + k < a.n) q = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)(R0 + k) * a.stride + R0 + j4);
+            *reinterpret_cast<f32x4acc *>(&C[k][j4]) = q;
+        }
+        __syncthreads();
+    }
+    unsigned long long xw = a.XT[(size_t)b * a.Rp + r];
+    unsigned long long accepted = 0;
+    bool any = false;
+    if (force) {
+        // field (re)initialisation: the "flips" are the set bits (f = diag + sum of the rows with x = 1)
+#pragma unroll 8
+        for (int k = 0; k < kXgB; ++k) {
+            const float sk = ((xw >> k) & 1ull) ? 1.0f : 0.0f;
+            a.S[(size_t)k * a.Rp + r] = sk;
+        }
+        any = xw != 0ull;
+    } else {
+        float t[kXgB], th[kXgB];
+#pragma unroll
+        for (int k = 0; k < kXgB; ++k) {
+            t[k] = a.F[fidx(a, R0 + k, r)];
+            th[k] = a.TH[((size_t)(b & 3) * 64 + k) * a.Rp + r];
+        }
+        static_for<0, kXgB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const bool xk = ((xw >> k) & 1ull) != 0ull;
+            const float dE = xk ? -t[k] : t[k];
+            const bool acc = dE < th[k];
+            const float sk = acc ? (xk ? -1.0f : 1.0f) : 0.0f;
+            a.S[(size_t)k * a.Rp + r] = sk;
+            if (acc) { xw ^= 1ull << k; ++accepted; }
+            if (__ballot(acc) != 0ull) {                       // (wave-uniform: nobody flipped row k -> nothing to add)
+#pragma unroll
+                for (int j = k + 1; j < kXgB; ++j) t[j] = __fmaf_rn(C[k][j], sk, t[j]);
+                any = any || acc;
+            }
+        });
+        a.XT[(size_t)b * a.Rp + r] = xw;
+    }
+    const unsigned long long anyb = __ballot(any);
+    if (lane == 0) a.flags[(size_t)(b & 1) * (a.Rp / kXgReps) + (r >> 6)] = anyb != 0ull ? 1u : 0u;
+    if (!force) {
+        // accepted flips of this wavefront -> stats[1]
+        unsigned long long tot = accepted;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+        if (lane == 0 && tot) atomicAdd(&a.stats[1], tot);
+    }
+}
+
+// ---- PANEL(b): F[col][r] += sum_k Q2[64 b + k][col] * S[k][r] ----
+// workgroup = 256 columns x 64 replicas, wave w = columns [64 w, 64 w + 64): 4 x 4 tiles, C[i = replica][j = column]
+__global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int b)
+{
+    constexpr int AS = kXgCols + 16, SS = kXgReps + 16;       // padded LDS strides: conflict-free operand reads
+    constexpr int CR = 16;                                    // rows of Q2 per chunk in LDS (the next chunk waits in registers)
+    __shared__ __attribute__((aligned(16))) float Apan[CR][AS];
+    __shared__ __attribute__((aligned(16))) float Ssl[kXgB][SS];
+    const int rx = blockIdx.x, cy = blockIdx.y;
+    if (a.flags[(size_t)(b & 1) * (a.Rp / kXgReps) + rx] == 0u) return;      // none of these 64 replicas flipped a row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int R0 = b * kXgB, col0 = cy * kXgCols, rep0 = rx * kXgReps;
+
+    // chunk c of the block's rows: thread t fetches 4 x 16 B (row = 4 i + t / 64, 4 columns at 4 (t % 64))
+    f32x4acc pre[CR / 4];
+    auto fetch_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < CR / 4; ++i) {
+            const int row = R0 + CR * c + 4 * i + (tid >> 6);
+            pre[i] = f32x4acc{0, 0, 0, 0};
+            if (row < a.n) pre[i] = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)row * a.stride + col0 + 4 * (tid & 63));
+        }
+    };
+    fetch_chunk(0);
+    // accumulators: tile (rt, ct): replicas rep0 + 16 rt + 4 lq + reg, column col0 + 64 wave + 16 ct + lr
+    f32x4acc acc[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+            acc[rt][ct] = *reinterpret_cast<const f32x4acc *>(
+                a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, rep0 + 16 * rt + 4 * lq));
+    // the signs of this block for these 64 replicas
+    for (int e = tid; e < kXgB * kXgReps / 4; e += 256) {
+        const int k = e >> 4, j4 = (e & 15) * 4;
+        *reinterpret_cast<f32x4acc *>(&Ssl[k][j4]) = *reinterpret_cast<const f32x4acc *>(a.S + (size_t)k * a.Rp + rep0 + j4);
+    }
+#pragma unroll 1
+    for (int c = 0; c < kXgB / CR; ++c) {
+        __syncthreads();                                       // (the previous chunk is consumed)
+#pragma unroll
+        for (int i = 0; i < CR / 4; ++i) *reinterpret_cast<f32x4acc *>(&Apan[4 * i + (tid >> 6)][4 * (tid & 63)]) = pre[i];
+        if (c + 1 < kXgB / CR) fetch_chunk(c + 1);             // in flight under this chunk's MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < CR / 4; ++ks) {                  // k = CR c + 4 ks + lq
+            float sa[4], qb[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) sa[rt] = Ssl[CR * c + 4 * ks + lq][16 * rt + lr];        // A[i = lr][k = lq]
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) qb[ct] = Apan[4 * ks + lq][64 * wave + 16 * ct + lr];    // B[k = lq][j = lr]
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[rt], qb[ct], acc[rt][ct], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+            *reinterpret_cast<f32x4acc *>(a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, rep0 + 16 * rt + 4 * lq)) = acc[rt][ct];
+}
+
+// ---- states out; energy E = 1/2 sum_i x_i (f_i + diag_i) from the cached fp32 fields, summed in fp64 (as K1x) ----
+__global__ void __launch_bounds__(64) k_xg_finish(XgArgs a)
+{
+    const int lane = threadIdx.x, r = blockIdx.x;                         // one wavefront per replica
+    double e = 0.0;
+    for (int b = 0; b < a.nblocks; ++b) {
+        const unsigned long long xw = a.XT[(size_t)b * a.Rp + r];
+        const int i = b * kXgB + lane;
+        const bool x = ((xw >> lane) & 1ull) != 0ull;
+        if (i < a.n) {
+            a.states[(size_t)r * a.n + i] = x ? 1 : 0;
+            if (x) e += 0.5 * ((double)a.F[fidx(a, i, r)] + (double)a.diag[i]);
+        }
+    }
+    e = wave_sum_f64(e);
+    if (lane == 0) a.energy[r] = e + a.offset;
+}
+
+}  // namespace
+
+size_t mi_dense_xg_workspace_bytes(int n, int R)
+{
+    const size_t Rp = ((size_t)R + 255) / 256 * 256, ncols = ((size_t)n + kXgCols - 1) / kXgCols * kXgCols;
+    const size_t nblocks = ((size_t)n + kXgB - 1) / kXgB;
+    return ncols * Rp * 4 + nblocks * Rp * 8 + (size_t)kXgB * Rp * 4 + 4 * 64 * Rp * 4 + 2 * (Rp / 64) * 4 + 256;
+}
+
+// The whole run: (re)initialisation passes and sweeps as K1x orders them; two launches per block of 64 rows.
+int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStream_t st)
+{
+    XgArgs a;
+    a.Q2 = x.Q2; a.diag = x.diag; a.stride = (size_t)chunks * 4096;
+    a.n = x.n; a.R = x.R; a.Rp = (x.R + 255) / 256 * 256;       // (whole DIAG workgroups; the idle seats never accept)
+    a.ncols = (x.n + kXgCols - 1) / kXgCols * kXgCols;
+    a.nblocks = (x.n + kXgB - 1) / kXgB;
+    char *w = static_cast<char *>(workspace);
+    a.F = reinterpret_cast<float *>(w);                      w += (size_t)a.ncols * a.Rp * 4;
+    a.XT = reinterpret_cast<unsigned long long *>(w);        w += (size_t)a.nblocks * a.Rp * 8;
+    a.S = reinterpret_cast<float *>(w);                      w += (size_t)kXgB * a.Rp * 4;
+    a.TH = reinterpret_cast<float *>(w);                     w += (size_t)4 * 64 * a.Rp * 4;
+    a.flags = reinterpret_cast<unsigned int *>(w);
+    a.temps = x.temps; a.init = x.init; a.states = x.states; a.energy = x.energy; a.stats = x.stats; a.offset = x.offset;
+    a.replica_offset = x.replica_offset; a.seed_lo = x.seed_lo; a.seed_hi = x.seed_hi;
+    a.temps_per_replica = x.temps_per_replica;
+    note_kernel("k_xg_diag + k_xg_panel (K1g, %d blocks of 64 rows)", a.nblocks);
+
+    HIP_TRY(hipMemsetAsync(a.XT, 0, (size_t)a.nblocks * a.Rp * 8, st));     // (replicas past R: no bits)
+    hipLaunchKernelGGL(k_xg_init_state, dim3(a.R, (a.nblocks + 3) / 4), dim3(64), 0, st, a);
+    const dim3 gdiag(a.Rp / 256), gpanel(a.Rp / kXgReps, a.ncols / kXgCols);
+    const dim3 gthr((a.Rp + 255) / 256, 64);
+    auto pass = [&](int force, uint32_t sweep, int s_local) {
+        for (int b = 0; b < a.nblocks; ++b) {
+            if (!force && (b & 3) == 0) hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, st, a, b >> 2, sweep, s_local);
+            hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, st, a, b, force);
+            hipLaunchKernelGGL(k_xg_panel, gpanel, dim3(256), 0, st, a, b);
+        }
+    };
+    int until_resync = x.resync > 0 ? 1 : 0;
+    for (int s = 0; s < x.num_sweeps; ++s) {
+        bool init_now = (s == 0);
+        if (x.resync > 0 && --until_resync == 0) { init_now = true; until_resync = x.resync; }
+        if (init_now) {
+            const size_t cells = (size_t)a.ncols * a.Rp;
+            hipLaunchKernelGGL(k_xg_fill_fields, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, a);
+            pass(1, 0u, 0);
+        }
+        pass(0, (uint32_t)s + x.sweep_offset, s);
+    }
+    if (x.num_sweeps == 0) {                                   // energies of the initial states
+        const size_t cells = (size_t)a.ncols * a.Rp;
+        hipLaunchKernelGGL(k_xg_fill_fields, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, a);
+        pass(1, 0u, 0);
+    }
+    hipLaunchKernelGGL(k_xg_finish, dim3(a.R), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace mi_sa_impl

@@ -164,6 +164,9 @@ struct mi_sa_problem {
     float *d_Qm = nullptr;       // K1m: plain row-major Q2 + diagonal row (NT <= 44)
     float *d_Qs = nullptr;       // plain row-major copy (energy kernel), allocated lazily
     float *d_Q2xl = nullptr, *d_diagxl = nullptr;   // K1x (n > 4096): padded rows of 2*Qs, diagonal
+    void *d_xg = nullptr;                    // K1g workspace (fields of all replicas, state words, signs, thresholds)
+    size_t xg_bytes = 0;
+    int opt_xl_batched = 0;                  // n > 4096: 0 auto (K1g for >= 256 replicas), 1 always K1g, 2 always K1x
     int xl_chunks = 0;
     // structured kinds (slot-ELL)
     int slots = 0, D = 0;
@@ -738,7 +741,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_pt_rung, p->d_pt_betas, p->d_pt_energy, p->d_pt_ladder, p->d_pt_stats, p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_xg, p->d_pt_rung, p->d_pt_betas, p->d_pt_energy, p->d_pt_ladder, p->d_pt_stats, p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -782,6 +785,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
 {
     if (!p || !key) return fail(MI_EINVAL, "NULL argument");
     if (!strcmp(key, "pace")) { p->opt_pace = value != 0; return MI_OK; }
+    if (!strcmp(key, "xl_batched") && value >= 0 && value <= 2) { p->opt_xl_batched = (int)value; return MI_OK; }
     if (!strcmp(key, "mfma_permille") && value >= 0 && value <= 1000) { p->opt_mfma_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "chunk_sweeps") && value >= 0) { p->opt_chunk_sweeps = (int)value; return MI_OK; }
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
@@ -844,8 +848,18 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
         p->last_launches = 1;
+        const bool batched = p->opt_xl_batched == 1 || (p->opt_xl_batched == 0 && R >= 256);
+        if (batched) {
+            const size_t need = mi_dense_xg_workspace_bytes(p->n, R);
+            if (need > p->xg_bytes) {
+                if (p->d_xg) HIP_TRY(hipFree(p->d_xg));
+                p->d_xg = nullptr; p->xg_bytes = 0;
+                HIP_TRY(hipMalloc(&p->d_xg, need));
+                p->xg_bytes = need;
+            }
+        }
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
-        rc = mi_launch_dense_xl(a, p->xl_chunks, p->stream);
+        rc = batched ? mi_launch_dense_xg(a, p->xl_chunks, p->d_xg, p->stream) : mi_launch_dense_xl(a, p->xl_chunks, p->stream);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
     } else if (p->kind == MI_KIND_DENSE) {

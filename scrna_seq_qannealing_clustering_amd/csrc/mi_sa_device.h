@@ -281,6 +281,9 @@ struct DenseXlArgs {
     int temps_per_replica;
 };
 int mi_launch_dense_xl(const DenseXlArgs &, int chunks, hipStream_t);
+// K1g (dense_xg_kernels.hip): the same run for many replicas at once, row updates as a GEMM-shaped pass per 64 rows
+size_t mi_dense_xg_workspace_bytes(int n, int R);
+int mi_launch_dense_xg(const DenseXlArgs &, int chunks, void *workspace, hipStream_t);
 
 // random word of (variable i, sweep s, global replica g, tag) -- the per-variable form of the chain's RNG
 // addressing (one Philox block per call; the wave kernels share a block between four slots instead)

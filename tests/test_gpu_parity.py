@@ -338,12 +338,44 @@ def test_dense_beyond_4096_variables_workgroup_per_replica(n, R, sweeps):
     for kw in (dict(), dict(init=init, resync_interval=2)):
         ost, oen, ostats = so.sa_dense_philox(Qs, R, betas, 11, replica_offset=5, **kw)
         with Problem.dense(Qs) as p:
-            p.anneal(R, betas, 11, replica_offset=5, initial_states=kw.get("init"),
-                     resync_interval=kw.get("resync_interval", 0))
-            st, en, info = p.fetch()
-        assert info["accepted"] == int(ostats[1]) and info["accepted"] > n // 10
-        assert np.array_equal(st, ost)
-        assert np.allclose(en, oen, rtol=1e-5, atol=1e-3)
+            # 2 = K1x (a workgroup per replica); 1 = K1g (all replicas together, 64 rows per GEMM-shaped pass on the matrix
+            # cores -- what runs of >= 256 replicas take by default)
+            for mode, name in ((2, "k_anneal_dense_xl"), (1, "k_xg_diag + k_xg_panel")):
+                p.set_option("xl_batched", mode)
+                p.anneal(R, betas, 11, replica_offset=5, initial_states=kw.get("init"),
+                         resync_interval=kw.get("resync_interval", 0))
+                st, en, info = p.fetch()
+                assert p.kernel_name().startswith(name)
+                assert info["accepted"] == int(ostats[1]) and info["accepted"] > n // 10
+                assert np.array_equal(st, ost)
+                assert np.allclose(en, oen, rtol=1e-5, atol=1e-3)
+
+
+def test_batched_dense_kernel_many_replicas_equal_workgroup_per_replica():
+    """K1g at the replica counts it is meant for (300 = 5 flag words, a ragged last DIAG workgroup) against K1x on the same
+    model: identical states, accepted counts and (cached-field) energies over a hot-to-cold schedule; zero sweeps return
+    the initial states with their energies."""
+    n, R = 4500, 300
+    rng = np.random.RandomState(5)
+    A = (rng.rand(n, n).astype(np.float32) - 0.5) * (rng.rand(n, n) < 0.02)
+    Qs = np.triu(A, 1)
+    Qs = np.ascontiguousarray(Qs + Qs.T)
+    Qs[np.arange(n), np.arange(n)] = rng.randn(n).astype(np.float32)
+    betas = np.geomspace(0.05, 20.0, 6)
+    with Problem.dense(Qs) as p:
+        p.anneal(R, betas, 3, resync_interval=4)
+        assert p.kernel_name().startswith("k_xg_diag")                      # the default for >= 256 replicas
+        st, en, info = p.fetch()
+        p.set_option("xl_batched", 2)
+        p.anneal(R, betas, 3, resync_interval=4)
+        assert p.kernel_name().startswith("k_anneal_dense_xl")
+        st2, en2, info2 = p.fetch()
+        assert np.array_equal(st, st2) and info["accepted"] == info2["accepted"] and info["accepted"] > R * n
+        assert np.allclose(en, en2, rtol=1e-6)
+        p.set_option("xl_batched", 1)
+        p.anneal(R, betas[:0], 3, initial_states=st)
+        st3, en3, _ = p.fetch()
+        assert np.array_equal(st3, st) and np.allclose(en3, en, rtol=1e-5)
 
 
 def test_full_size_properties_config4_dense_50k():
