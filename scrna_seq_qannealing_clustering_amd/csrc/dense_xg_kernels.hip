@@ -18,8 +18,10 @@
 //             are simply dropped.
 // A Q row is read once per sweep for all replicas (10.6 GB per sweep at n = 50 000 instead of 213 KB per accepted
 // flip and replica); what the pass costs is the read-modify-write of F (n_pad x R x 8 B per block) and
-// 2 * 64 * n_pad * R flop per block on the matrix pipe.  Two launches per block (stream order is the chain's
-// order); thresholds for four blocks at a time (one Philox block serves four 64-variable slots).
+// 2 * 64 * n_pad * R flop per block on the matrix pipe.  The read-modify-write is paid once per GROUP of four
+// blocks: inside a group the later blocks' own columns get the earlier blocks' rows by small passes into a side
+// buffer (Tm), so that their DIAGs can run before the group's full pass.  Stream order is the chain's order;
+// thresholds for four blocks at a time (one Philox block serves four 64-variable slots).
 // Used for R >= 256 replicas; K1x keeps the small batches.
 #include "mi_sa_device.h"
 
@@ -39,9 +41,10 @@ struct XgArgs {
     float *F;               // cached fields, [Rp / 64][ncols][64]: the 64 replicas of a PANEL workgroup contiguous per
                             // column, so that its 256 x 64 tile is ONE 64 KB run of memory (see fidx)
     unsigned long long *XT; // [nblocks][Rp] state bits of a block, bit k = x of variable 64 b + k
-    float *S;               // [64][Rp] signs of the current block
+    float *S;               // [4][64][Rp] signs of the four blocks of the current group
+    float *Tm;              // [Rp / 64][3][64][64] fields of the group's blocks 1..3 with the earlier blocks' rows applied (tmidx)
     float *TH;              // [4][64][Rp] thresholds of four consecutive blocks
-    unsigned int *flags;    // [2][Rp / 64]
+    unsigned int *flags;    // [4][Rp / 64]: block j of the group flipped something in these 64 replicas
     const float *temps;
     const uint8_t *init;    // nullable, R x n
     uint8_t *states;        // R x n
@@ -56,6 +59,11 @@ struct XgArgs {
 __device__ __forceinline__ size_t fidx(const XgArgs &a, int col, int r)
 {
     return ((size_t)(r >> 6) * a.ncols + col) * 64 + (r & 63);
+}
+
+__device__ __forceinline__ size_t tmidx(int slot, int col, int r)
+{
+    return (((size_t)(r >> 6) * 3 + slot) * 64 + col) * 64 + (r & 63);
 }
 
 // ---- state bits: XT[b][r] from the given initial states or the chain's own random start (tag 1) ----
@@ -100,13 +108,15 @@ __global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_
     for (int c = 0; c < 4; ++c) a.TH[((size_t)c * 64 + lane) * a.Rp + r] = th[c];
 }
 
-// ---- DIAG(b): one thread per replica ----
+// ---- DIAG(b): one thread per replica.  j = b % 4: position in its group of four blocks -- block 0 reads its fields
+// from F, the others from Tm (F plus the rows of the group's earlier blocks, k_xg_panel<true>) ----
 __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force)
 {
     __shared__ __attribute__((aligned(16))) float C[kXgB][kXgB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = blockIdx.x * 256 + tid;
-    const int R0 = b * kXgB;
+    const int R0 = b * kXgB, j = b & 3;
+    float *Sj = a.S + (size_t)j * kXgB * a.Rp;
     if (!force) {
         // coupling block: row R0 + k (zero past n), columns R0 .. R0 + 63
         for (int e = tid; e < kXgB * kXgB / 4; e += 256) {
@@ -125,15 +135,15 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force)
 #pragma unroll 8
         for (int k = 0; k < kXgB; ++k) {
             const float sk = ((xw >> k) & 1ull) ? 1.0f : 0.0f;
-            a.S[(size_t)k * a.Rp + r] = sk;
+            Sj[(size_t)k * a.Rp + r] = sk;
         }
         any = xw != 0ull;
     } else {
         float t[kXgB], th[kXgB];
 #pragma unroll
         for (int k = 0; k < kXgB; ++k) {
-            t[k] = a.F[fidx(a, R0 + k, r)];
-            th[k] = a.TH[((size_t)(b & 3) * 64 + k) * a.Rp + r];
+            t[k] = j == 0 ? a.F[fidx(a, R0 + k, r)] : a.Tm[tmidx(j - 1, k, r)];
+            th[k] = a.TH[((size_t)j * 64 + k) * a.Rp + r];
         }
         static_for<0, kXgB>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -141,18 +151,18 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force)
             const float dE = xk ? -t[k] : t[k];
             const bool acc = dE < th[k];
             const float sk = acc ? (xk ? -1.0f : 1.0f) : 0.0f;
-            a.S[(size_t)k * a.Rp + r] = sk;
+            Sj[(size_t)k * a.Rp + r] = sk;
             if (acc) { xw ^= 1ull << k; ++accepted; }
             if (__ballot(acc) != 0ull) {                       // (wave-uniform: nobody flipped row k -> nothing to add)
 #pragma unroll
-                for (int j = k + 1; j < kXgB; ++j) t[j] = __fmaf_rn(C[k][j], sk, t[j]);
+                for (int jj = k + 1; jj < kXgB; ++jj) t[jj] = __fmaf_rn(C[k][jj], sk, t[jj]);
                 any = any || acc;
             }
         });
         a.XT[(size_t)b * a.Rp + r] = xw;
     }
     const unsigned long long anyb = __ballot(any);
-    if (lane == 0) a.flags[(size_t)(b & 1) * (a.Rp / kXgReps) + (r >> 6)] = anyb != 0ull ? 1u : 0u;
+    if (lane == 0) a.flags[(size_t)j * (a.Rp / kXgReps) + (r >> 6)] = anyb != 0ull ? 1u : 0u;
     if (!force) {
         // accepted flips of this wavefront -> stats[1]
         unsigned long long tot = accepted;
@@ -162,71 +172,97 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force)
     }
 }
 
-// ---- PANEL(b): F[col][r] += sum_k Q2[64 b + k][col] * S[k][r] ----
-// workgroup = 256 columns x 64 replicas, wave w = columns [64 w, 64 w + 64): 4 x 4 tiles, C[i = replica][j = column]
-__global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int b)
+// ---- PANEL: fields (+)= sum over rows of Q2[row][col] * S[row][r], the rows in order, as chained MFMAs ----
+// workgroup = 256 columns x 64 replicas, wave w = 64 columns: 4 x 4 tiles, C[i = replica][j = column].
+//   MINI = false: the whole group g (blocks 4 g .. 4 g + nbg - 1, 64 nbg rows) onto ALL columns of F -- F is read and
+//                 written once per 256 rows, which is what this pass costs besides the MFMAs;
+//   MINI = true:  the rows of block 4 g + j alone onto the columns of the group's LATER blocks (wave w: block
+//                 4 g + j + 1 + w), into Tm -- the fields the next DIAGs of the group decide on.  F itself is
+//                 untouched until the group's full pass, which applies the same rows in the same order.
+template <bool MINI>
+__global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, int j)
 {
     constexpr int AS = kXgCols + 16, SS = kXgReps + 16;       // padded LDS strides: conflict-free operand reads
     constexpr int CR = 16;                                    // rows of Q2 per chunk in LDS (the next chunk waits in registers)
     __shared__ __attribute__((aligned(16))) float Apan[CR][AS];
     __shared__ __attribute__((aligned(16))) float Ssl[kXgB][SS];
-    const int rx = blockIdx.x, cy = blockIdx.y;
-    if (a.flags[(size_t)(b & 1) * (a.Rp / kXgReps) + rx] == 0u) return;      // none of these 64 replicas flipped a row
+    const int rx = blockIdx.x, cy = blockIdx.y, ranges = a.Rp / kXgReps;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const int R0 = b * kXgB, col0 = cy * kXgCols, rep0 = rx * kXgReps;
+    const int rep0 = rx * kXgReps;
+    const int jb0 = MINI ? j : 0, jb1 = MINI ? j + 1 : nbg;   // row blocks of the group this pass applies
+    const int col0 = MINI ? (4 * g + j + 1) * kXgB : cy * kXgCols;
+    unsigned int live = 0;                                    // bit jj: block jj flipped a row in these 64 replicas
+    for (int jj = jb0; jj < jb1; ++jj) live |= (a.flags[(size_t)jj * ranges + rx] != 0u ? 1u : 0u) << jj;
+    if (live == 0u && !(MINI && j == 0)) return;              // (the first MINI of a group also COPIES F into Tm)
+    const bool wave_on = !MINI || wave < nbg - 1 - j;         // MINI: one wave per later block of the group
 
-    // chunk c of the block's rows: thread t fetches 4 x 16 B (row = 4 i + t / 64, 4 columns at 4 (t % 64))
     f32x4acc pre[CR / 4];
-    auto fetch_chunk = [&](int c) {
+    auto fetch_chunk = [&](int jj, int c) {                   // rows 16 c .. 16 c + 15 of block 4 g + jj, columns col0 ..
 #pragma unroll
         for (int i = 0; i < CR / 4; ++i) {
-            const int row = R0 + CR * c + 4 * i + (tid >> 6);
+            const int row = (4 * g + jj) * kXgB + CR * c + 4 * i + (tid >> 6), col = col0 + 4 * (tid & 63);
             pre[i] = f32x4acc{0, 0, 0, 0};
-            if (row < a.n) pre[i] = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)row * a.stride + col0 + 4 * (tid & 63));
+            if (row < a.n && (size_t)col < a.stride) pre[i] = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)row * a.stride + col);
         }
     };
-    fetch_chunk(0);
-    // accumulators: tile (rt, ct): replicas rep0 + 16 rt + 4 lq + reg, column col0 + 64 wave + 16 ct + lr
+    // accumulators: tile (rt, ct): replicas rep0 + 16 rt + 4 lq + reg, column 64 wave + 16 ct + lr of the workgroup's 256
+    auto field_ptr = [&](bool dst, int ct, int rt) -> float * {
+        const int r = rep0 + 16 * rt + 4 * lq;
+        if (MINI) {
+            if (!dst && j == 0) return a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, r);
+            return a.Tm + tmidx(j + wave, 16 * ct + lr, r);
+        }
+        return a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, r);
+    };
     f32x4acc acc[4][4];
+    if (wave_on) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-            acc[rt][ct] = *reinterpret_cast<const f32x4acc *>(
-                a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, rep0 + 16 * rt + 4 * lq));
-    // the signs of this block for these 64 replicas
-    for (int e = tid; e < kXgB * kXgReps / 4; e += 256) {
-        const int k = e >> 4, j4 = (e & 15) * 4;
-        *reinterpret_cast<f32x4acc *>(&Ssl[k][j4]) = *reinterpret_cast<const f32x4acc *>(a.S + (size_t)k * a.Rp + rep0 + j4);
+            for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = *reinterpret_cast<const f32x4acc *>(field_ptr(false, ct, rt));
     }
 #pragma unroll 1
-    for (int c = 0; c < kXgB / CR; ++c) {
-        __syncthreads();                                       // (the previous chunk is consumed)
+    for (int jj = jb0; jj < jb1; ++jj) {
+        if (!((live >> jj) & 1u)) continue;                   // uniform: no flip of this block in these replicas
+        fetch_chunk(jj, 0);
+        __syncthreads();                                       // (Ssl of the previous block consumed)
+        for (int e = tid; e < kXgB * kXgReps / 4; e += 256) {
+            const int k = e >> 4, j4 = (e & 15) * 4;
+            *reinterpret_cast<f32x4acc *>(&Ssl[k][j4]) =
+                *reinterpret_cast<const f32x4acc *>(a.S + ((size_t)jj * kXgB + k) * a.Rp + rep0 + j4);
+        }
+#pragma unroll 1
+        for (int c = 0; c < kXgB / CR; ++c) {
+            __syncthreads();                                   // (the previous chunk is consumed)
 #pragma unroll
-        for (int i = 0; i < CR / 4; ++i) *reinterpret_cast<f32x4acc *>(&Apan[4 * i + (tid >> 6)][4 * (tid & 63)]) = pre[i];
-        if (c + 1 < kXgB / CR) fetch_chunk(c + 1);             // in flight under this chunk's MFMAs
-        __syncthreads();
+            for (int i = 0; i < CR / 4; ++i) *reinterpret_cast<f32x4acc *>(&Apan[4 * i + (tid >> 6)][4 * (tid & 63)]) = pre[i];
+            if (c + 1 < kXgB / CR) fetch_chunk(jj, c + 1);     // in flight under this chunk's MFMAs
+            __syncthreads();
+            if (wave_on) {
 #pragma unroll
-        for (int ks = 0; ks < CR / 4; ++ks) {                  // k = CR c + 4 ks + lq
-            float sa[4], qb[4];
+                for (int ks = 0; ks < CR / 4; ++ks) {          // k = CR c + 4 ks + lq
+                    float sa[4], qb[4];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) sa[rt] = Ssl[CR * c + 4 * ks + lq][16 * rt + lr];        // A[i = lr][k = lq]
+                    for (int rt = 0; rt < 4; ++rt) sa[rt] = Ssl[CR * c + 4 * ks + lq][16 * rt + lr];        // A[i = lr][k = lq]
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) qb[ct] = Apan[4 * ks + lq][64 * wave + 16 * ct + lr];    // B[k = lq][j = lr]
+                    for (int ct = 0; ct < 4; ++ct) qb[ct] = Apan[4 * ks + lq][64 * wave + 16 * ct + lr];    // B[k = lq][j = lr]
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+                    for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[rt], qb[ct], acc[rt][ct], 0, 0, 0);
+                        for (int rt = 0; rt < 4; ++rt)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[rt], qb[ct], acc[rt][ct], 0, 0, 0);
+                }
+            }
         }
     }
+    if (wave_on) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-            *reinterpret_cast<f32x4acc *>(a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, rep0 + 16 * rt + 4 * lq)) = acc[rt][ct];
+            for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4acc *>(field_ptr(true, ct, rt)) = acc[rt][ct];
+    }
 }
 
 // ---- states out; energy E = 1/2 sum_i x_i (f_i + diag_i) from the cached fp32 fields, summed in fp64 (as K1x) ----
@@ -253,7 +289,7 @@ size_t mi_dense_xg_workspace_bytes(int n, int R)
 {
     const size_t Rp = ((size_t)R + 255) / 256 * 256, ncols = ((size_t)n + kXgCols - 1) / kXgCols * kXgCols;
     const size_t nblocks = ((size_t)n + kXgB - 1) / kXgB;
-    return ncols * Rp * 4 + nblocks * Rp * 8 + (size_t)kXgB * Rp * 4 + 4 * 64 * Rp * 4 + 2 * (Rp / 64) * 4 + 256;
+    return ncols * Rp * 4 + nblocks * Rp * 8 + 4 * (size_t)kXgB * Rp * 4 + 3 * 64 * Rp * 4 + 4 * 64 * Rp * 4 + 4 * (Rp / 64) * 4 + 256;
 }
 
 // The whole run: (re)initialisation passes and sweeps as K1x orders them; two launches per block of 64 rows.
@@ -267,23 +303,29 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     char *w = static_cast<char *>(workspace);
     a.F = reinterpret_cast<float *>(w);                      w += (size_t)a.ncols * a.Rp * 4;
     a.XT = reinterpret_cast<unsigned long long *>(w);        w += (size_t)a.nblocks * a.Rp * 8;
-    a.S = reinterpret_cast<float *>(w);                      w += (size_t)kXgB * a.Rp * 4;
+    a.S = reinterpret_cast<float *>(w);                      w += 4 * (size_t)kXgB * a.Rp * 4;
+    a.Tm = reinterpret_cast<float *>(w);                     w += 3 * (size_t)64 * a.Rp * 4;
     a.TH = reinterpret_cast<float *>(w);                     w += (size_t)4 * 64 * a.Rp * 4;
     a.flags = reinterpret_cast<unsigned int *>(w);
     a.temps = x.temps; a.init = x.init; a.states = x.states; a.energy = x.energy; a.stats = x.stats; a.offset = x.offset;
     a.replica_offset = x.replica_offset; a.seed_lo = x.seed_lo; a.seed_hi = x.seed_hi;
     a.temps_per_replica = x.temps_per_replica;
-    note_kernel("k_xg_diag + k_xg_panel (K1g, %d blocks of 64 rows)", a.nblocks);
+    note_kernel("k_xg_diag + k_xg_panel (K1g, %d blocks of 64 rows in groups of 4)", a.nblocks);
 
     HIP_TRY(hipMemsetAsync(a.XT, 0, (size_t)a.nblocks * a.Rp * 8, st));     // (replicas past R: no bits)
     hipLaunchKernelGGL(k_xg_init_state, dim3(a.R, (a.nblocks + 3) / 4), dim3(64), 0, st, a);
     const dim3 gdiag(a.Rp / 256), gpanel(a.Rp / kXgReps, a.ncols / kXgCols);
     const dim3 gthr((a.Rp + 255) / 256, 64);
+    const dim3 gmini(a.Rp / kXgReps, 1);
     auto pass = [&](int force, uint32_t sweep, int s_local) {
-        for (int b = 0; b < a.nblocks; ++b) {
-            if (!force && (b & 3) == 0) hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, st, a, b >> 2, sweep, s_local);
-            hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, st, a, b, force);
-            hipLaunchKernelGGL(k_xg_panel, gpanel, dim3(256), 0, st, a, b);
+        for (int g = 0; 4 * g < a.nblocks; ++g) {
+            const int nbg = a.nblocks - 4 * g < 4 ? a.nblocks - 4 * g : 4;
+            if (!force) hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, st, a, g, sweep, s_local);
+            for (int j = 0; j < nbg; ++j) {
+                hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, st, a, 4 * g + j, force);
+                if (!force && j + 1 < nbg) hipLaunchKernelGGL(k_xg_panel<true>, gmini, dim3(256), 0, st, a, g, nbg, j);
+            }
+            hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, st, a, g, nbg, 0);
         }
     };
     int until_resync = x.resync > 0 ? 1 : 0;
