@@ -24,6 +24,7 @@
 // thresholds for four blocks at a time (one Philox block serves four 64-variable slots).
 // Used for R >= 256 replicas; K1x keeps the small batches.
 #include "mi_sa_device.h"
+#include <vector>
 
 namespace mi_sa_impl {
 namespace {
@@ -41,10 +42,10 @@ struct XgArgs {
     float *F;               // cached fields, [Rp / 64][ncols][64]: the 64 replicas of a PANEL workgroup contiguous per
                             // column, so that its 256 x 64 tile is ONE 64 KB run of memory (see fidx)
     unsigned long long *XT; // [nblocks][Rp] state bits of a block, bit k = x of variable 64 b + k
-    float *S;               // [4][64][Rp] signs of the four blocks of the current group
+    float *S;               // [2][4][64][Rp] signs of the four blocks of a group (two groups in flight: parity)
     float *Tm;              // [Rp / 64][3][64][64] fields of the group's blocks 1..3 with the earlier blocks' rows applied (tmidx)
     float *TH;              // [4][64][Rp] thresholds of four consecutive blocks
-    unsigned int *flags;    // [4][Rp / 64]: block j of the group flipped something in these 64 replicas
+    unsigned int *flags;    // [2][4][Rp / 64]: block j of the group flipped something in these 64 replicas
     const float *temps;
     const uint8_t *init;    // nullable, R x n
     uint8_t *states;        // R x n
@@ -110,13 +111,13 @@ __global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_
 
 // ---- DIAG(b): one thread per replica.  j = b % 4: position in its group of four blocks -- block 0 reads its fields
 // from F, the others from Tm (F plus the rows of the group's earlier blocks, k_xg_panel<true>) ----
-__global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force)
+__global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force, int par)
 {
     __shared__ __attribute__((aligned(16))) float C[kXgB][kXgB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = blockIdx.x * 256 + tid;
     const int R0 = b * kXgB, j = b & 3;
-    float *Sj = a.S + (size_t)j * kXgB * a.Rp;
+    float *Sj = a.S + ((size_t)par * 4 + j) * kXgB * a.Rp;
     if (!force) {
         // coupling block: row R0 + k (zero past n), columns R0 .. R0 + 63
         for (int e = tid; e < kXgB * kXgB / 4; e += 256) {
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force)
         a.XT[(size_t)b * a.Rp + r] = xw;
     }
     const unsigned long long anyb = __ballot(any);
-    if (lane == 0) a.flags[(size_t)j * (a.Rp / kXgReps) + (r >> 6)] = anyb != 0ull ? 1u : 0u;
+    if (lane == 0) a.flags[((size_t)par * 4 + j) * (a.Rp / kXgReps) + (r >> 6)] = anyb != 0ull ? 1u : 0u;
     if (!force) {
         // accepted flips of this wavefront -> stats[1]
         unsigned long long tot = accepted;
@@ -179,14 +180,17 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force)
 //   MINI = true:  the rows of block 4 g + j alone onto the columns of the group's LATER blocks (wave w: block
 //                 4 g + j + 1 + w), into Tm -- the fields the next DIAGs of the group decide on.  F itself is
 //                 untouched until the group's full pass, which applies the same rows in the same order.
+// The full pass of a group is launched in two parts: first the 256 columns that are the NEXT group's own (cy_only), then
+// the rest (cy_skip) -- the next group's DIAGs need only the first part and run beside the second (dense_xg host loop).
 template <bool MINI>
-__global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, int j)
+__global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, int j, int par, int cy_only, int cy_skip)
 {
     constexpr int AS = kXgCols + 16, SS = kXgReps + 16;       // padded LDS strides: conflict-free operand reads
     constexpr int CR = 16;                                    // rows of Q2 per chunk in LDS (the next chunk waits in registers)
     __shared__ __attribute__((aligned(16))) float Apan[CR][AS];
     __shared__ __attribute__((aligned(16))) float Ssl[kXgB][SS];
-    const int rx = blockIdx.x, cy = blockIdx.y, ranges = a.Rp / kXgReps;
+    const int rx = blockIdx.x, cy = cy_only >= 0 ? cy_only : (int)blockIdx.y, ranges = a.Rp / kXgReps;
+    if (!MINI && cy == cy_skip) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -194,7 +198,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     const int jb0 = MINI ? j : 0, jb1 = MINI ? j + 1 : nbg;   // row blocks of the group this pass applies
     const int col0 = MINI ? (4 * g + j + 1) * kXgB : cy * kXgCols;
     unsigned int live = 0;                                    // bit jj: block jj flipped a row in these 64 replicas
-    for (int jj = jb0; jj < jb1; ++jj) live |= (a.flags[(size_t)jj * ranges + rx] != 0u ? 1u : 0u) << jj;
+    for (int jj = jb0; jj < jb1; ++jj) live |= (a.flags[((size_t)par * 4 + jj) * ranges + rx] != 0u ? 1u : 0u) << jj;
     if (live == 0u && !(MINI && j == 0)) return;              // (the first MINI of a group also COPIES F into Tm)
     const bool wave_on = !MINI || wave < nbg - 1 - j;         // MINI: one wave per later block of the group
 
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
         for (int e = tid; e < kXgB * kXgReps / 4; e += 256) {
             const int k = e >> 4, j4 = (e & 15) * 4;
             *reinterpret_cast<f32x4acc *>(&Ssl[k][j4]) =
-                *reinterpret_cast<const f32x4acc *>(a.S + ((size_t)jj * kXgB + k) * a.Rp + rep0 + j4);
+                *reinterpret_cast<const f32x4acc *>(a.S + (((size_t)par * 4 + jj) * kXgB + k) * a.Rp + rep0 + j4);
         }
 #pragma unroll 1
         for (int c = 0; c < kXgB / CR; ++c) {
@@ -289,7 +293,7 @@ size_t mi_dense_xg_workspace_bytes(int n, int R)
 {
     const size_t Rp = ((size_t)R + 255) / 256 * 256, ncols = ((size_t)n + kXgCols - 1) / kXgCols * kXgCols;
     const size_t nblocks = ((size_t)n + kXgB - 1) / kXgB;
-    return ncols * Rp * 4 + nblocks * Rp * 8 + 4 * (size_t)kXgB * Rp * 4 + 3 * 64 * Rp * 4 + 4 * 64 * Rp * 4 + 4 * (Rp / 64) * 4 + 256;
+    return ncols * Rp * 4 + nblocks * Rp * 8 + 8 * (size_t)kXgB * Rp * 4 + 3 * 64 * Rp * 4 + 4 * 64 * Rp * 4 + 8 * (Rp / 64) * 4 + 256;
 }
 
 // The whole run: (re)initialisation passes and sweeps as K1x orders them; two launches per block of 64 rows.
@@ -303,7 +307,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     char *w = static_cast<char *>(workspace);
     a.F = reinterpret_cast<float *>(w);                      w += (size_t)a.ncols * a.Rp * 4;
     a.XT = reinterpret_cast<unsigned long long *>(w);        w += (size_t)a.nblocks * a.Rp * 8;
-    a.S = reinterpret_cast<float *>(w);                      w += 4 * (size_t)kXgB * a.Rp * 4;
+    a.S = reinterpret_cast<float *>(w);                      w += 8 * (size_t)kXgB * a.Rp * 4;
     a.Tm = reinterpret_cast<float *>(w);                     w += 3 * (size_t)64 * a.Rp * 4;
     a.TH = reinterpret_cast<float *>(w);                     w += (size_t)4 * 64 * a.Rp * 4;
     a.flags = reinterpret_cast<unsigned int *>(w);
@@ -317,35 +321,107 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     const dim3 gdiag(a.Rp / 256), gpanel(a.Rp / kXgReps, a.ncols / kXgCols);
     const dim3 gthr((a.Rp + 255) / 256, 64);
     const dim3 gmini(a.Rp / kXgReps, 1);
-    auto pass = [&](int force, uint32_t sweep, int s_local) {
-        for (int g = 0; 4 * g < a.nblocks; ++g) {
-            const int nbg = a.nblocks - 4 * g < 4 ? a.nblocks - 4 * g : 4;
-            if (!force) hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, st, a, g, sweep, s_local);
-            for (int j = 0; j < nbg; ++j) {
-                hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, st, a, 4 * g + j, force);
-                if (!force && j + 1 < nbg) hipLaunchKernelGGL(k_xg_panel<true>, gmini, dim3(256), 0, st, a, g, nbg, j);
+    // Each stream gets its own compute units: the chain's kernels are small (4 .. 16 workgroups) and latency-critical,
+    // and behind a full pass that keeps every CU filled from its 3000-workgroup grid they were not scheduled until
+    // the pass had drained (measured: a 23 us DIAG took 234 us) -- 8 of the 256 CUs are set aside for them.
+    hipStream_t sa = st, sb = st;                             // (fallback without CU masks: one stream, same order)
+    bool own_streams = false;
+    {
+        int dev = 0, ncu = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        const int words = (ncu + 31) / 32;
+        std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
+        for (int c = 0; c < ncu; ++c) (c < 8 ? mb : ma)[(size_t)c / 32] |= 1u << (c % 32);
+        hipStream_t ta = nullptr, tb = nullptr;
+        if (ncu >= 64 && hipExtStreamCreateWithCUMask(&ta, (uint32_t)words, ma.data()) == hipSuccess) {
+            if (hipExtStreamCreateWithCUMask(&tb, (uint32_t)words, mb.data()) == hipSuccess) {
+                sa = ta; sb = tb; own_streams = true;
+            } else {
+                (void)hipStreamDestroy(ta);
             }
-            hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, st, a, g, nbg, 0);
         }
-    };
-    int until_resync = x.resync > 0 ? 1 : 0;
-    for (int s = 0; s < x.num_sweeps; ++s) {
-        bool init_now = (s == 0);
-        if (x.resync > 0 && --until_resync == 0) { init_now = true; until_resync = x.resync; }
-        if (init_now) {
+        (void)hipGetLastError();
+    }
+    hipEvent_t ev_in, ev_out;
+    HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev_in, st));                       // everything enqueued on the caller's stream so far
+    if (own_streams) { HIP_TRY(hipStreamWaitEvent(sa, ev_in, 0)); HIP_TRY(hipStreamWaitEvent(sb, ev_in, 0)); }
+    // Two streams.  B runs the chain of a group (thresholds, DIAG, MINI); A rewrites F (the group's full pass), in two
+    // parts: the 256 columns the NEXT group owns go to B, in front of that group's chain (a sixteen-workgroup launch);
+    // all others to A, beside that chain.  A group's full pass needs its signs (evS);
+    // the S / flag buffers of a parity are free again when the full pass two groups back is through (evP).  Forced
+    // (re-initialisation) groups decide nothing and read no fields; the first real group after them waits for all of F.
+    hipEvent_t evS[4], evP[4], evQ[4];
+    for (int i = 0; i < 4; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&evS[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&evP[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&evQ[i], hipEventDisableTiming));
+    }
+    const int ngroups = (a.nblocks + 3) / 4;
+    long G = 0;                                               // running group count
+    // the list of passes: (force, sweep index)
+    struct Pass { int force; uint32_t sweep; int s_local; };
+    std::vector<Pass> passes;
+    {
+        int until_resync = x.resync > 0 ? 1 : 0;
+        for (int s = 0; s < x.num_sweeps; ++s) {
+            bool init_now = (s == 0);
+            if (x.resync > 0 && --until_resync == 0) { init_now = true; until_resync = x.resync; }
+            if (init_now) passes.push_back({1, 0u, 0});
+            passes.push_back({0, (uint32_t)s + x.sweep_offset, s});
+        }
+        if (x.num_sweeps == 0) passes.push_back({1, 0u, 0});  // energies of the initial states
+    }
+    bool split_prev = false;                                  // the previous group's full pass was launched in two parts
+    for (size_t pi = 0; pi < passes.size(); ++pi) {
+        const Pass &ps = passes[pi];
+        if (ps.force) {                                       // F = diag, on A, after everything that still reads F
+            HIP_TRY(hipEventRecord(evS[(G + 3) & 3], sb));
+            HIP_TRY(hipStreamWaitEvent(sa, evS[(G + 3) & 3], 0));
             const size_t cells = (size_t)a.ncols * a.Rp;
-            hipLaunchKernelGGL(k_xg_fill_fields, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, a);
-            pass(1, 0u, 0);
+            hipLaunchKernelGGL(k_xg_fill_fields, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, sa, a);
         }
-        pass(0, (uint32_t)s + x.sweep_offset, s);
+        for (int g = 0; g < ngroups; ++g, ++G) {
+            const int nbg = a.nblocks - 4 * g < 4 ? a.nblocks - 4 * g : 4;
+            const int par = (int)(G & 1);
+            const bool last_of_pass = g + 1 == ngroups;
+            const bool has_next = !last_of_pass || pi + 1 < passes.size();
+            const int next_force = last_of_pass ? (has_next ? passes[pi + 1].force : 1) : ps.force;
+            // ---- stream B: the chain of group G
+            if (G >= 2) HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 2) & 3], 0));        // S / flags of this parity are free
+            if (!ps.force && G >= 1 && !split_prev)                                   // its own columns of F are final: the
+                HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 1) & 3], 0));                 // previous full pass (or its first part, on B)
+            if (!ps.force) hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, sb, a, g, ps.sweep, ps.s_local);
+            for (int j = 0; j < nbg; ++j) {
+                hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, sb, a, 4 * g + j, ps.force, par);
+                if (!ps.force && j + 1 < nbg)
+                    hipLaunchKernelGGL(k_xg_panel<true>, gmini, dim3(256), 0, sb, a, g, nbg, j, par, -1, -1);
+            }
+            HIP_TRY(hipEventRecord(evS[G & 3], sb));
+            // ---- the group's full pass over F: the next group's own 256 columns on B (in front of that group's chain; they
+            // must hold everything up to group G - 1 first), all others on A
+            HIP_TRY(hipStreamWaitEvent(sa, evS[G & 3], 0));
+            split_prev = has_next && !next_force && ngroups > 1;
+            if (split_prev) {
+                const int gn = last_of_pass ? 0 : g + 1;
+                if (G >= 1) HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 1) & 3], 0));
+                hipLaunchKernelGGL(k_xg_panel<false>, gmini, dim3(256), 0, sb, a, g, nbg, 0, par, gn, -1);
+                hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, gn);
+            } else {
+                hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, -1);
+            }
+            HIP_TRY(hipEventRecord(evP[G & 3], sa));
+        }
     }
-    if (x.num_sweeps == 0) {                                   // energies of the initial states
-        const size_t cells = (size_t)a.ncols * a.Rp;
-        hipLaunchKernelGGL(k_xg_fill_fields, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, a);
-        pass(1, 0u, 0);
-    }
-    hipLaunchKernelGGL(k_xg_finish, dim3(a.R), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_xg_finish, dim3(a.R), dim3(64), 0, sa, a);          // (A has waited for the last signs: evS)
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev_out, sa));
+    if (own_streams) HIP_TRY(hipStreamWaitEvent(st, ev_out, 0));             // the caller's stream continues after the run
+    for (int i = 0; i < 4; ++i) { HIP_TRY(hipEventDestroy(evS[i])); HIP_TRY(hipEventDestroy(evP[i])); HIP_TRY(hipEventDestroy(evQ[i])); }
+    HIP_TRY(hipEventDestroy(ev_in)); HIP_TRY(hipEventDestroy(ev_out));
+    if (own_streams) { HIP_TRY(hipStreamDestroy(sa)); HIP_TRY(hipStreamDestroy(sb)); }   // (deferred until drained)
     return MI_OK;
 }
 

@@ -400,6 +400,11 @@ def test_full_size_properties_config4_dense_50k():
         p.anneal(2, betas, 77, replica_offset=4094)
         st, en, info = p.fetch()
         assert p.kernel_name().startswith("k_anneal_dense_xl<13>")
+        p.set_option("xl_batched", 1)                         # K1g: the same two replicas through the batched passes
+        p.anneal(2, betas, 77, replica_offset=4094)
+        stg, eng, infog = p.fetch()
+        assert p.kernel_name().startswith("k_xg_diag")
+        assert np.array_equal(stg, st) and infog["accepted"] == info["accepted"] and np.allclose(eng, en, rtol=1e-6)
     ost, oen, ostats = so.sa_dense_philox(Qs, 2, betas, 77, replica_offset=4094)
     del Qs
     assert info["proposals"] == 2 * 2 * n and info["accepted"] == int(ostats[1]) and info["accepted"] > 100
