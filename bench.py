@@ -21,7 +21,8 @@ per launch (adjacency + linear terms of every slot of every sweep of every wavef
 shape; the TCC_REQ counter of profiles/r02_* agrees) / mean launch time (HIP events), `peak` = 34.5 TB/s
 (MI355X_MICROARCH.md, L2 aggregate), `traffic` = what the fabric counters saw (HBM side).  `effective` keeps
 SURVEY.md 8d's per-update byte model (deg_i*8 + 8) as an effective-bandwidth figure with no fraction.  The one
-kernel that really streams Q from HBM (K1x, n = 50 000 dense) is reported under `other_kernels.dense_xl_50k`.
+shape whose Q really lives in HBM (n = 50 000 dense, 10.6 GB; kernel K1g) is reported under
+`other_kernels.dense_xl_50k` with its MFMA roofline.
 `cpu_baseline` times the oracle on this host: the neal restatement (value), the SAME chain as the GPU kernel
 (`same_chain`) and the neal restatement at equal reads and sweeps (`equal_reads`).
 """
@@ -243,13 +244,16 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
     return out
 
 
-def dense_xl_50k(rank_device, n=50000, replicas=256, sweeps=4):
-    """BASELINE config 4 in its literal form -- the one kernel of the path that really streams Q from HBM: a
-    synthetic 50 000-cell SNN graph built on the GPU (snn.build_snn), the clustering_bqm QUBO as a dense fp32
-    matrix (10.6 GB resident in HBM), K1x (one workgroup per replica; an ACCEPTED flip streams one padded row of
-    Q), the first `sweeps` sweeps of the 1000-step schedule.  `hbm_roofline` = what rocprofv3 FETCH_SIZE x 2 saw on
-    this shape (profiles/r02_dense50k.json) against the 8 TB/s spec peak; `row_model` = the 4 n-byte row model -- the
-    replicas walk the rows in the same order, so the Infinity Cache serves most of those reads."""
+def dense_xl_50k(rank_device, n=50000, replicas=1024, sweeps=4):
+    """BASELINE config 4 in its literal form: a synthetic 50 000-cell SNN graph built on the GPU (snn.build_snn), the
+    clustering_bqm QUBO as a dense fp32 matrix (10.6 GB resident in HBM), one GPU's share of the replicas (8192 / 8), the
+    first `sweeps` sweeps of the 1000-step schedule (the hot end: > 99 % of the proposals are accepted).  Kernel K1g:
+    all replicas walk the rows together, 64 rows per DIAG, the row updates of a group of 256 rows as one GEMM-shaped
+    pass over F[column][replica] on the matrix cores.  `mfma_roofline` = its flop (2 x rows x columns x replicas per
+    pass, the field initialisation pass included) against the f32-input MFMA peak; `field_traffic` = the
+    read-modify-write of F per group of 256 rows; `hbm_side` = what rocprofv3 FETCH_SIZE x 2 saw on this shape
+    (profiles/r02_dense50k.json).  K1x (a workgroup per replica, one Q row per accepted flip) is what batches below
+    256 replicas run: 3.5e7 updates/s on this model."""
     from scrna_seq_qannealing_clustering_amd import models, snn
     from scrna_seq_qannealing_clustering_amd.engine import Problem
     rng = np.random.RandomState(1)
@@ -272,24 +276,27 @@ def dense_xl_50k(rank_device, n=50000, replicas=256, sweeps=4):
         ms = p.kernel_ms()
         kname = p.kernel_name()
         _, en, info = p.fetch(states=False)
-    n_pad = ((n + 4095) // 4096) * 4096
-    rows_streamed = info["accepted"] + replicas * n // 2          # + field initialisation: ~n/2 rows per replica
-    row_gbps = rows_streamed * 4.0 * n_pad / (ms * 1e-3) / 1e9
+    nblocks, ncols, rp = (n + 63) // 64, ((n + 255) // 256) * 256, ((replicas + 255) // 256) * 256
+    passes = sweeps + 1                                                           # + the field initialisation pass
+    flop = 2.0 * (64 * nblocks) * ncols * rp * passes
+    f_bytes = 8.0 * ncols * rp * ((nblocks + 3) // 4) * passes
     rec = _profile_json("r02_dense50k.json")
     hbm = None
     if rec and rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("n") == n:
-        hbm = {"bound": "hbm", "achieved": rec["fabric_read_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-               "frac": rec["fabric_read_GBps"] / HBM_PEAK_GBPS,
-               "source": "profiles/r02_dense50k.json: rocprofv3 --pmc FETCH_SIZE x 2 on this shape (scripts/pmc_dense50k.sh)"}
+        gbps = rec["pmc"]["fabric_read_bytes_x2"] / (ms * 1e-3) / 1e9
+        hbm = {"bytes": rec["pmc"]["fabric_read_bytes_x2"], "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+               "source": "profiles/r02_dense50k.json: rocprofv3 --pmc FETCH_SIZE x 2 on this shape (scripts/pmc_dense50k.sh), "
+                         "bytes of that run / this run's kernel time"}
     return {"kernel": kname, "n": n, "replicas": replicas, "sweeps": sweeps, "kernel_ms": ms,
             "updates_per_s": replicas * sweeps * n / (ms * 1e-3), "acceptance": info["accepted"] / info["proposals"],
-            "dense_Q_bytes": 4 * n * n_pad, "graph_edges": int(len(m.col) // 2),
-            "hbm_roofline": hbm,
-            "row_model": {"GBps": row_gbps, "bytes_per_accepted_flip": 4 * n_pad,
-                          "note": "4 * n_pad bytes of Q per ACCEPTED flip (SURVEY.md 8d: 4n per proposal; a rejected proposal needs "
-                                  "no row with cached fields) / kernel time: what the workgroups request.  The replicas walk the "
-                                  "rows in step at the hot end of the schedule, so L2 / Infinity Cache serve most of it: the HBM "
-                                  "side sees `hbm_roofline.achieved`"},
+            "dense_Q_bytes": 4 * n * (((n + 4095) // 4096) * 4096), "graph_edges": int(len(m.col) // 2),
+            "mfma_roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                              "frac": flop / (ms * 1e-3) / 157.3e12,
+                              "model": "2 x (64 x blocks) rows x padded columns x padded replicas per pass, all rows, "
+                                       "accepted or not (v_mfma_f32_16x16x4_f32 chained in row order: bit-exact)"},
+            "field_traffic": {"GBps": f_bytes / (ms * 1e-3) / 1e9,
+                              "note": "read + write of the cached fields F[column][replica] once per group of 256 rows"},
+            "hbm_side": hbm,
             "host_build_s": t_build, "upload_s": t_upload, "best_energy": float(en.min())}
 
 
