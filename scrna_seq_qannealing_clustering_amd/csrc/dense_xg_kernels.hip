@@ -297,8 +297,11 @@ size_t mi_dense_xg_workspace_bytes(int n, int R)
 }
 
 // The whole run: (re)initialisation passes and sweeps as K1x orders them; two launches per block of 64 rows.
-int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStream_t st)
+const float *mi_dense_xg_fields(void *workspace) { return static_cast<const float *>(workspace); }
+
+int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStream_t st, int phase)
 {
+    const bool begin = (phase & 1) != 0, end = (phase & 2) != 0;
     XgArgs a;
     a.Q2 = x.Q2; a.diag = x.diag; a.stride = (size_t)chunks * 4096;
     a.n = x.n; a.R = x.R; a.Rp = (x.R + 255) / 256 * 256;       // (whole DIAG workgroups; the idle seats never accept)
@@ -316,8 +319,10 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     a.temps_per_replica = x.temps_per_replica;
     note_kernel("k_xg_diag + k_xg_panel (K1g, %d blocks of 64 rows in groups of 4)", a.nblocks);
 
-    HIP_TRY(hipMemsetAsync(a.XT, 0, (size_t)a.nblocks * a.Rp * 8, st));     // (replicas past R: no bits)
-    hipLaunchKernelGGL(k_xg_init_state, dim3(a.R, (a.nblocks + 3) / 4), dim3(64), 0, st, a);
+    if (begin) {
+        HIP_TRY(hipMemsetAsync(a.XT, 0, (size_t)a.nblocks * a.Rp * 8, st));     // (replicas past R: no bits)
+        hipLaunchKernelGGL(k_xg_init_state, dim3(a.R, (a.nblocks + 3) / 4), dim3(64), 0, st, a);
+    }
     const dim3 gdiag(a.Rp / 256), gpanel(a.Rp / kXgReps, a.ncols / kXgCols);
     const dim3 gthr((a.Rp + 255) / 256, 64);
     const dim3 gmini(a.Rp / kXgReps, 1);
@@ -367,12 +372,12 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     {
         int until_resync = x.resync > 0 ? 1 : 0;
         for (int s = 0; s < x.num_sweeps; ++s) {
-            bool init_now = (s == 0);
+            bool init_now = (s == 0) && begin;                // (a continued run keeps its fields; it has no re-syncs)
             if (x.resync > 0 && --until_resync == 0) { init_now = true; until_resync = x.resync; }
             if (init_now) passes.push_back({1, 0u, 0});
             passes.push_back({0, (uint32_t)s + x.sweep_offset, s});
         }
-        if (x.num_sweeps == 0) passes.push_back({1, 0u, 0});  // energies of the initial states
+        if (x.num_sweeps == 0 && begin) passes.push_back({1, 0u, 0});  // energies of the initial states
     }
     bool split_prev = false;                                  // the previous group's full pass was launched in two parts
     for (size_t pi = 0; pi < passes.size(); ++pi) {
@@ -415,7 +420,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
             HIP_TRY(hipEventRecord(evP[G & 3], sa));
         }
     }
-    hipLaunchKernelGGL(k_xg_finish, dim3(a.R), dim3(64), 0, sa, a);          // (A has waited for the last signs: evS)
+    if (end) hipLaunchKernelGGL(k_xg_finish, dim3(a.R), dim3(64), 0, sa, a);          // (A has waited for the last signs: evS)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev_out, sa));
     if (own_streams) HIP_TRY(hipStreamWaitEvent(st, ev_out, 0));             // the caller's stream continues after the run

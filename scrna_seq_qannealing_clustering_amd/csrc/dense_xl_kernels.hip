@@ -94,7 +94,19 @@ __global__ void __launch_bounds__(kXlThreads) k_anneal_dense_xl(DenseXlArgs a)
     for (int s = 0; s < a.num_sweeps; ++s) {
         bool init_now = (s == 0);
         if (a.resync > 0 && --until_resync == 0) { init_now = true; until_resync = a.resync; }
-        if (init_now) field_init();
+        if (init_now && s == 0 && a.fields_in) {
+            // continue a run of K1g: its cached fields, exactly (a re-evaluation would round differently)
+            static_for<0, CH>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+#pragma unroll
+                for (int c = 0; c < V; ++c) {
+                    const int i = k * kXlChunk + tid * V + c;
+                    f[k][c] = i < a.fin_ncols ? a.fields_in[((size_t)(r >> 6) * a.fin_ncols + i) * 64 + (r & 63)] : 0.0f;
+                }
+            });
+        } else if (init_now) {
+            field_init();
+        }
         const float T = a.temps[a.temps_per_replica ? r : s];
         static_for<0, CH>([&](auto kc) {                         // compile-time chunk index: f[] stays in registers
             constexpr int k = decltype(kc)::value;

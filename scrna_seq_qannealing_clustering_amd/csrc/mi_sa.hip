@@ -167,6 +167,8 @@ struct mi_sa_problem {
     void *d_xg = nullptr;                    // K1g workspace (fields of all replicas, state words, signs, thresholds)
     size_t xg_bytes = 0;
     int opt_xl_batched = 0;                  // n > 4096: 0 auto (K1g for >= 256 replicas), 1 always K1g, 2 always K1x
+    int opt_xl_chunk = 8;                    // K1g: sweeps per chunk of a cooling run (the hand-over to K1x is decided per chunk)
+    int opt_xl_cold_permille = 20;           // hand the rest of the run to K1x when a chunk accepted less than this share (0 = never)
     int xl_chunks = 0;
     // structured kinds (slot-ELL)
     int slots = 0, D = 0;
@@ -786,6 +788,8 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!p || !key) return fail(MI_EINVAL, "NULL argument");
     if (!strcmp(key, "pace")) { p->opt_pace = value != 0; return MI_OK; }
     if (!strcmp(key, "xl_batched") && value >= 0 && value <= 2) { p->opt_xl_batched = (int)value; return MI_OK; }
+    if (!strcmp(key, "xl_chunk") && value >= 1) { p->opt_xl_chunk = (int)value; return MI_OK; }
+    if (!strcmp(key, "xl_cold_permille") && value >= 0 && value <= 1000) { p->opt_xl_cold_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "mfma_permille") && value >= 0 && value <= 1000) { p->opt_mfma_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "chunk_sweeps") && value >= 0) { p->opt_chunk_sweeps = (int)value; return MI_OK; }
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
@@ -859,7 +863,40 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
             }
         }
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
-        rc = batched ? mi_launch_dense_xg(a, p->xl_chunks, p->d_xg, p->stream) : mi_launch_dense_xl(a, p->xl_chunks, p->stream);
+        if (!batched) {
+            rc = mi_launch_dense_xl(a, p->xl_chunks, p->stream);
+        } else if (resync_interval > 0 || per_replica || num_sweeps <= p->opt_xl_chunk || p->opt_xl_cold_permille == 0) {
+            rc = mi_launch_dense_xg(a, p->xl_chunks, p->d_xg, p->stream, 3);
+        } else {
+            // K1g costs the same hot or cold (two launches per 64 rows whether anything flips or not); K1x costs per
+            // accepted flip.  Along a cooling schedule: K1g in chunks of sweeps while the chunks accept enough, then
+            // K1x for the rest, continuing from K1g's states AND cached fields (same chain, bit for bit).  The hand-over
+            // is decided on the host: this call waits for the hot chunks.
+            int s0 = 0;
+            while (!rc && s0 < num_sweeps) {
+                const int len = num_sweeps - s0 < p->opt_xl_chunk ? num_sweeps - s0 : p->opt_xl_chunk;
+                DenseXlArgs b = a;
+                b.num_sweeps = len; b.temps = a.temps + s0; b.sweep_offset = a.sweep_offset + (uint32_t)s0;
+                unsigned long long before = 0, after = 0;
+                HIP_TRY(hipMemcpyAsync(&before, p->d_stats + 1, sizeof before, hipMemcpyDeviceToHost, p->stream));
+                rc = mi_launch_dense_xg(b, p->xl_chunks, p->d_xg, p->stream, (s0 == 0 ? 1 : 0) | 2);
+                if (rc) break;
+                s0 += len;
+                if (s0 >= num_sweeps) break;
+                HIP_TRY(hipMemcpyAsync(&after, p->d_stats + 1, sizeof after, hipMemcpyDeviceToHost, p->stream));
+                HIP_TRY(hipStreamSynchronize(p->stream));
+                const double share = (double)(after - before) / ((double)R * (double)p->n * (double)len);
+                if (share * 1000.0 < (double)p->opt_xl_cold_permille) {
+                    DenseXlArgs c = a;
+                    c.num_sweeps = num_sweeps - s0; c.temps = a.temps + s0; c.sweep_offset = a.sweep_offset + (uint32_t)s0;
+                    c.init = (const uint8_t *)p->d_states;             // written by the chunk that just ended
+                    c.fields_in = mi_dense_xg_fields(p->d_xg);
+                    c.fin_ncols = (p->n + 255) / 256 * 256;
+                    rc = mi_launch_dense_xl(c, p->xl_chunks, p->stream);
+                    break;
+                }
+            }
+        }
         if (rc) return rc;
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
     } else if (p->kind == MI_KIND_DENSE) {

@@ -279,11 +279,17 @@ struct DenseXlArgs {
     int n, R, num_sweeps, resync;
     uint32_t replica_offset, seed_lo, seed_hi, sweep_offset;
     int temps_per_replica;
+    // K1x continuing a run of K1g: the cached fields of all replicas as K1g keeps them, F[r / 64][column][r % 64]
+    // (fin_ncols columns per replica range); nullptr = build the fields from the states (as at the start of a run)
+    const float *fields_in = nullptr;
+    int fin_ncols = 0;
 };
 int mi_launch_dense_xl(const DenseXlArgs &, int chunks, hipStream_t);
 // K1g (dense_xg_kernels.hip): the same run for many replicas at once, row updates as a GEMM-shaped pass per 64 rows
 size_t mi_dense_xg_workspace_bytes(int n, int R);
-int mi_launch_dense_xg(const DenseXlArgs &, int chunks, void *workspace, hipStream_t);
+// phase: bit 0 = first call of a run (state words, field initialisation), bit 1 = write states and energies
+int mi_launch_dense_xg(const DenseXlArgs &, int chunks, void *workspace, hipStream_t, int phase);
+const float *mi_dense_xg_fields(void *workspace);
 
 // random word of (variable i, sweep s, global replica g, tag) -- the per-variable form of the chain's RNG
 // addressing (one Philox block per call; the wave kernels share a block between four slots instead)

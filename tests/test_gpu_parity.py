@@ -376,6 +376,26 @@ def test_batched_dense_kernel_many_replicas_equal_workgroup_per_replica():
         p.anneal(R, betas[:0], 3, initial_states=st)
         st3, en3, _ = p.fetch()
         assert np.array_equal(st3, st) and np.allclose(en3, en, rtol=1e-5)
+        # a cooling run: K1g in chunks of two sweeps while they accept > 30 %, then K1x for the rest, continuing from K1g's
+        # states and cached fields -- the same chain as either kernel alone
+        cool = np.geomspace(0.02, 40.0, 12)
+        p.set_option("xl_batched", 2)
+        p.anneal(R, cool, 9)
+        ref = p.fetch()
+        p.set_option("xl_batched", 0)
+        p.set_option("xl_chunk", 2)
+        p.set_option("xl_cold_permille", 300)
+        p.anneal(R, cool, 9)
+        name = p.kernel_name()
+        got = p.fetch()
+        assert "k_xg_diag" in name and "k_anneal_dense_xl" in name
+        assert np.array_equal(got[0], ref[0]) and got[2]["accepted"] == ref[2]["accepted"]
+        assert np.allclose(got[1], ref[1], rtol=1e-6)
+        p.set_option("xl_cold_permille", 0)                   # never hand over: K1g alone, same result
+        p.anneal(R, cool, 9)
+        assert "dense_xl" not in p.kernel_name()
+        alone = p.fetch()
+        assert np.array_equal(alone[0], ref[0]) and alone[2]["accepted"] == ref[2]["accepted"]
 
 
 def test_full_size_properties_config4_dense_50k():
