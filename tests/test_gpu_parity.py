@@ -396,6 +396,16 @@ def test_batched_dense_kernel_many_replicas_equal_workgroup_per_replica():
         assert "dense_xl" not in p.kernel_name()
         alone = p.fetch()
         assert np.array_equal(alone[0], ref[0]) and alone[2]["accepted"] == ref[2]["accepted"]
+        # one constant temperature per replica (a tempering round), continued from the states on the device with the
+        # random stream of sweep 12 onwards: both kernels again
+        rung = np.geomspace(0.05, 5.0, R)
+        outs = []
+        for mode in (2, 1):
+            p.set_option("xl_batched", mode)
+            p.anneal(R, cool[:3], 9)
+            p.anneal(R, rung, 9, num_sweeps=2, sweep_offset=3, continue_run=True)
+            outs.append(p.fetch())
+        assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][2]["accepted"] == outs[1][2]["accepted"]
 
 
 def test_full_size_properties_config4_dense_50k():
