@@ -299,6 +299,28 @@ size_t mi_dense_xg_workspace_bytes(int n, int R)
 // The whole run: (re)initialisation passes and sweeps as K1x orders them; two launches per block of 64 rows.
 const float *mi_dense_xg_fields(void *workspace) { return static_cast<const float *>(workspace); }
 
+namespace {
+// the run's own streams and events: released on every way out of the launcher (the runtime defers the destruction of
+// a stream or event that still has work in flight)
+struct XgSync {
+    hipStream_t sa = nullptr, sb = nullptr;
+    bool own_streams = false;
+    hipEvent_t ev[10] = {};
+    int nev = 0;
+    ~XgSync()
+    {
+        for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+        if (own_streams) { (void)hipStreamDestroy(sa); (void)hipStreamDestroy(sb); }
+    }
+    int event(hipEvent_t *out)
+    {
+        HIP_TRY(hipEventCreateWithFlags(out, hipEventDisableTiming));
+        ev[nev++] = *out;
+        return MI_OK;
+    }
+};
+}  // namespace
+
 int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStream_t st, int phase)
 {
     const bool begin = (phase & 1) != 0, end = (phase & 2) != 0;
@@ -329,6 +351,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     // Each stream gets its own compute units: the chain's kernels are small (4 .. 16 workgroups) and latency-critical,
     // and behind a full pass that keeps every CU filled from its 3000-workgroup grid they were not scheduled until
     // the pass had drained (measured: a 23 us DIAG took 234 us) -- 8 of the 256 CUs are set aside for them.
+    XgSync sync;
     hipStream_t sa = st, sb = st;                             // (fallback without CU masks: one stream, same order)
     bool own_streams = false;
     {
@@ -342,6 +365,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
         if (ncu >= 64 && hipExtStreamCreateWithCUMask(&ta, (uint32_t)words, ma.data()) == hipSuccess) {
             if (hipExtStreamCreateWithCUMask(&tb, (uint32_t)words, mb.data()) == hipSuccess) {
                 sa = ta; sb = tb; own_streams = true;
+                sync.sa = ta; sync.sb = tb; sync.own_streams = true;
             } else {
                 (void)hipStreamDestroy(ta);
             }
@@ -349,8 +373,8 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
         (void)hipGetLastError();
     }
     hipEvent_t ev_in, ev_out;
-    HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+    if (int rc = sync.event(&ev_in)) return rc;
+    if (int rc = sync.event(&ev_out)) return rc;
     HIP_TRY(hipEventRecord(ev_in, st));                       // everything enqueued on the caller's stream so far
     if (own_streams) { HIP_TRY(hipStreamWaitEvent(sa, ev_in, 0)); HIP_TRY(hipStreamWaitEvent(sb, ev_in, 0)); }
     // Two streams.  B runs the chain of a group (thresholds, DIAG, MINI); A rewrites F (the group's full pass), in two
@@ -358,11 +382,10 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     // all others to A, beside that chain.  A group's full pass needs its signs (evS);
     // the S / flag buffers of a parity are free again when the full pass two groups back is through (evP).  Forced
     // (re-initialisation) groups decide nothing and read no fields; the first real group after them waits for all of F.
-    hipEvent_t evS[4], evP[4], evQ[4];
+    hipEvent_t evS[4], evP[4];
     for (int i = 0; i < 4; ++i) {
-        HIP_TRY(hipEventCreateWithFlags(&evS[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&evP[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&evQ[i], hipEventDisableTiming));
+        if (int rc = sync.event(&evS[i])) return rc;
+        if (int rc = sync.event(&evP[i])) return rc;
     }
     const int ngroups = (a.nblocks + 3) / 4;
     long G = 0;                                               // running group count
@@ -424,9 +447,6 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev_out, sa));
     if (own_streams) HIP_TRY(hipStreamWaitEvent(st, ev_out, 0));             // the caller's stream continues after the run
-    for (int i = 0; i < 4; ++i) { HIP_TRY(hipEventDestroy(evS[i])); HIP_TRY(hipEventDestroy(evP[i])); HIP_TRY(hipEventDestroy(evQ[i])); }
-    HIP_TRY(hipEventDestroy(ev_in)); HIP_TRY(hipEventDestroy(ev_out));
-    if (own_streams) { HIP_TRY(hipStreamDestroy(sa)); HIP_TRY(hipStreamDestroy(sb)); }   // (deferred until drained)
     return MI_OK;
 }
 
