@@ -390,12 +390,20 @@ def main():
     effective = alg_bytes / (launch_ms * 1e-3) / 1e9
     accept = info["accepted"] / info["proposals"]
     if args.kernel == "dense":
-        # K1w: rows come out of the LDS ring / L2, only accepted flips need one: no memory roofline bounds it
-        # (LDS -> VGPR fill rate); the byte model is an effective figure only
-        row_bytes = info["accepted"] * (((n + 255) // 256) * 256 * 4)   # padded rows the accepted flips consumed
-        roofline = {"bound": "lds_fill", "achieved": row_bytes / (k_ms * 1e-3) / 1e9, "peak": 157000.0, "unit": "GB/s",
-                    "frac": row_bytes / (k_ms * 1e-3) / 1e9 / 157000.0, "traffic": None,
-                    "model": "padded Q rows moved from LDS into registers by accepted flips; peak = 256 B/clk/CU x 256 CUs"}
+        # Two kernels serve a cooling run: K1m the hot chunks (fields as MFMA accumulators: every row
+        # costs 2 * 16 * n_pad flop per workgroup, accepted or not), K1w the rest (rows leave the LDS ring only for accepted
+        # flips).  The roofline object prices the MFMA work of the K1m chunks against the f32-input MFMA peak over the
+        # WHOLE step time (K1w's share of the time included): a lower bound of the fraction.
+        ds = prob.debug_stats()
+        mfma_chunks = int(ds[15])
+        mfma_sweeps = min(len(betas), 8 + 32 * max(mfma_chunks - 1, 0)) if mfma_chunks else 0
+        n_pad = ((n + 255) // 256) * 256
+        flop = 2.0 * 16 * n_pad * (((n + 15) // 16) * 16) * ((R + 15) // 16) * mfma_sweeps
+        roofline = {"bound": "mfma", "achieved": flop / (k_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": flop / (k_ms * 1e-3) / 157.3e12, "traffic": None,
+                    "mfma_sweeps": mfma_sweeps, "mfma_chunks": mfma_chunks, "workgroup_kernel_chunks": int(ds[14]),
+                    "model": "flop of the sweeps K1m served (2 x 16 x n_pad x rows per workgroup and sweep) / the time of the whole "
+                             "step, K1w's sweeps included; K1m alone: 0.49 of the peak (profiles/r02_k1m_binding.json)"}
     else:
         ell_width = 16 if np.diff(m.rowptr).max() <= 16 else (32 if np.diff(m.rowptr).max() <= 32 else 64)
         l2_bytes = l2_request_bytes_per_launch(kernel_name, R, sweeps_per_launch, n, ell_width)

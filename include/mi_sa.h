@@ -123,7 +123,8 @@ int mi_sa_plan_slot_layout(const int32_t *rowptr, const int32_t *col, int n, int
 int mi_sa_problem_set_absent(mi_sa_problem *p, const uint8_t *absent);
 
 /* Diagnostic: copies the first `words` (<= 16) 64-bit statistics words of the last run ([0..2] as in
- * mi_sa_fetch; [8..12] per-phase cycle sums of builds compiled with -DMI_K2_PROFILE, otherwise 0). */
+ * mi_sa_fetch; [8..12] per-phase cycle sums of builds compiled with -DMI_K2_PROFILE, otherwise 0; with words = 16,
+ * [14] / [15] = chunks of the last scheduled dense run served by the workgroup kernel / the MFMA kernel). */
 int mi_sa_debug_stats(mi_sa_problem *p, uint64_t *out, int words);
 
 /* ---- the anneal (replaces the sampler call itself) ------------------------------------------- */

@@ -770,6 +770,11 @@ int mi_sa_debug_stats(mi_sa_problem *p, uint64_t *out, int words)
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (words > 16) words = 16;
     HIP_TRY(hipMemcpy(out, p->d_stats, (size_t)words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (words == 16 && p->d_ctrl) {                         // [14], [15]: chunks of the last scheduled dense run served by K1w / K1m
+        unsigned int c[2] = {0, 0};
+        HIP_TRY(hipMemcpy(c, p->d_ctrl + 4, sizeof c, hipMemcpyDeviceToHost));
+        out[14] = c[0]; out[15] = c[1];
+    }
     return MI_OK;
 }
 
