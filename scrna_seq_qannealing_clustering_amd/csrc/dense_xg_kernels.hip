@@ -24,6 +24,7 @@
 // thresholds for four blocks at a time (one Philox block serves four 64-variable slots).
 // Used for R >= 256 replicas; K1x keeps the small batches.
 #include "mi_sa_device.h"
+#include <cstdlib>
 #include <vector>
 
 namespace mi_sa_impl {
@@ -362,7 +363,8 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
         std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
         for (int c = 0; c < ncu; ++c) (c < 8 ? mb : ma)[(size_t)c / 32] |= 1u << (c % 32);
         hipStream_t ta = nullptr, tb = nullptr;
-        if (ncu >= 64 && hipExtStreamCreateWithCUMask(&ta, (uint32_t)words, ma.data()) == hipSuccess) {
+        const char *one = getenv("MI_XG_ONE_STREAM");       // (tests: the fallback order on the caller's stream)
+        if (!(one && one[0] == '1') && ncu >= 64 && hipExtStreamCreateWithCUMask(&ta, (uint32_t)words, ma.data()) == hipSuccess) {
             if (hipExtStreamCreateWithCUMask(&tb, (uint32_t)words, mb.data()) == hipSuccess) {
                 sa = ta; sb = tb; own_streams = true;
                 sync.sa = ta; sync.sb = tb; sync.own_streams = true;

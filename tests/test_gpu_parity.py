@@ -396,6 +396,15 @@ def test_batched_dense_kernel_many_replicas_equal_workgroup_per_replica():
         assert "dense_xl" not in p.kernel_name()
         alone = p.fetch()
         assert np.array_equal(alone[0], ref[0]) and alone[2]["accepted"] == ref[2]["accepted"]
+        import os
+        os.environ["MI_XG_ONE_STREAM"] = "1"                  # without CU-masked streams: the same kernels in one stream
+        try:
+            p.set_option("xl_batched", 1)
+            p.anneal(R, cool, 9)
+            one = p.fetch()
+        finally:
+            del os.environ["MI_XG_ONE_STREAM"]
+        assert np.array_equal(one[0], ref[0]) and one[2]["accepted"] == ref[2]["accepted"]
         # one constant temperature per replica (a tempering round), continued from the states on the device with the
         # random stream of sweep 12 onwards: both kernels again
         rung = np.geomspace(0.05, 5.0, R)
