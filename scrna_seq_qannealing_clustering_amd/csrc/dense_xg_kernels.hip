@@ -5,7 +5,7 @@
 // and streams one 4 n-byte row of Q per accepted flip through it: at n = 50 000 that is 213 KB behind a barrier and a
 // full L2 round trip per flip (7.7 us), and every replica fetches every row for itself.  Here all R replicas walk
 // the rows TOGETHER, 64 rows (one "block") at a time, with the cached fields of all replicas in HBM / Infinity
-// Cache as F[column][replica]:
+// Cache as F[replica range][column][64 replicas]:
 //   DIAG(b)   one thread per replica: the 64 decisions of block b in sequence, on the replica's 64 fields of the
 //             block's own columns and the 64 x 64 coupling block Q2[b][b] (LDS, broadcast reads) -- leaves the signs
 //             S[k][r] in {-1, 0, +1} (0 = rejected), the new state bits, and a "some replica flipped" flag per
@@ -20,9 +20,10 @@
 // flip and replica); what the pass costs is the read-modify-write of F (n_pad x R x 8 B per block) and
 // 2 * 64 * n_pad * R flop per block on the matrix pipe.  The read-modify-write is paid once per GROUP of four
 // blocks: inside a group the later blocks' own columns get the earlier blocks' rows by small passes into a side
-// buffer (Tm), so that their DIAGs can run before the group's full pass.  Stream order is the chain's order;
-// thresholds for four blocks at a time (one Philox block serves four 64-variable slots).
-// Used for R >= 256 replicas; K1x keeps the small batches.
+// buffer (Tm), so that their DIAGs can run before the group's full pass.  The chain of the NEXT group runs on a second
+// stream with 8 compute units of its own beside the current group's full pass (events order them; see the launcher).
+// Thresholds for four blocks at a time (one Philox block serves four 64-variable slots).
+// Used for R >= 256 replicas; K1x keeps the small batches and the cold end of a cooling run (mi_sa.hip).
 #include "mi_sa_device.h"
 #include <cstdlib>
 #include <vector>
