@@ -444,6 +444,17 @@ def test_full_size_properties_config4_dense_50k():
         stg, eng, infog = p.fetch()
         assert p.kernel_name().startswith("k_xg_diag")
         assert np.array_equal(stg, st) and infog["accepted"] == info["accepted"] and np.allclose(eng, en, rtol=1e-6)
+        # and a full first wave of workgroups: 256 replicas x 1 sweep at the hot end, K1g (its default) against K1x
+        hot = models.make_beta_schedule(1000, models.default_beta_range(m))[:1]
+        p.set_option("xl_batched", 0)
+        p.anneal(256, hot, 5)
+        assert p.kernel_name().startswith("k_xg_diag")
+        sg, eg, ig = p.fetch()
+        p.set_option("xl_batched", 2)
+        p.anneal(256, hot, 5)
+        sx, ex, ix = p.fetch()
+        assert np.array_equal(sg, sx) and ig["accepted"] == ix["accepted"] and ig["accepted"] > 0.99 * 256 * n
+        assert np.allclose(eg, ex, rtol=1e-6)
     ost, oen, ostats = so.sa_dense_philox(Qs, 2, betas, 77, replica_offset=4094)
     del Qs
     assert info["proposals"] == 2 * 2 * n and info["accepted"] == int(ostats[1]) and info["accepted"] > 100
