@@ -6,7 +6,7 @@
 // full L2 round trip per flip (7.7 us), and every replica fetches every row for itself.  Here all R replicas walk
 // the rows TOGETHER, 64 rows (one "block") at a time, with the cached fields of all replicas in HBM / Infinity
 // Cache as F[replica range][column][64 replicas]:
-//   DIAG(b)   one thread per replica: the 64 decisions of block b in sequence, on the replica's 64 fields of the
+//   DIAG(b)   four lanes per replica: the 64 decisions of block b in sequence, on the replica's 64 fields of the
 //             block's own columns and the 64 x 64 coupling block Q2[b][b] (LDS, broadcast reads) -- leaves the signs
 //             S[k][r] in {-1, 0, +1} (0 = rejected), the new state bits, and a "some replica flipped" flag per
 //             64 replicas;
@@ -111,61 +111,82 @@ __global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_
     for (int c = 0; c < 4; ++c) a.TH[((size_t)c * 64 + lane) * a.Rp + r] = th[c];
 }
 
-// ---- DIAG(b): one thread per replica.  j = b % 4: position in its group of four blocks -- block 0 reads its fields
-// from F, the others from Tm (F plus the rows of the group's earlier blocks, k_xg_panel<true>) ----
+// ---- DIAG(b): FOUR lanes per replica (a quad), 64 replicas per workgroup.  Lane q of a quad holds the fields of the
+// block's columns q, 4 + q, ..., 60 + q; step k decides row k in lane q = k % 4, the sign goes round the quad by DPP,
+// every lane applies the coupling row to its 16 fields (those of rows already decided are dead and may take
+// garbage) -- a quarter of the fmaf chain per lane of the one-thread-per-replica form (25 -> 10 us per block).
+// j = b % 4: position in its group of four blocks -- block 0 reads its fields from F, the others from Tm (F plus the
+// rows of the group's earlier blocks, k_xg_panel<true>) ----
+template <int QK>
+__device__ __forceinline__ float xg_quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), QK * 0x55, 0xf, 0xf, false));
+}
+
 __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force, int par)
 {
-    __shared__ __attribute__((aligned(16))) float C[kXgB][kXgB];
+    __shared__ __attribute__((aligned(16))) float Ct[kXgB][4][16];       // Ct[k][q][m] = Q2[R0 + k][R0 + q + 4 m]
+    __shared__ int any_s;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int r = blockIdx.x * 256 + tid;
+    const int q = tid & 3, r = blockIdx.x * 64 + (tid >> 2);
     const int R0 = b * kXgB, j = b & 3;
     float *Sj = a.S + ((size_t)par * 4 + j) * kXgB * a.Rp;
+    if (tid == 0) any_s = 0;
     if (!force) {
-        // coupling block: row R0 + k (zero past n), columns R0 .. R0 + 63
         for (int e = tid; e < kXgB * kXgB / 4; e += 256) {
-            const int k = e >> 4, j4 = (e & 15) * 4;
-            f32x4acc q = {0, 0, 0, 0};
-            if (R0 + k < a.n) q = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)(R0 + k) * a.stride + R0 + j4);
-            *reinterpret_cast<f32x4acc *>(&C[k][j4]) = q;
+            const int k = e >> 4, c = e & 15;                             // columns R0 + 4 c .. + 3: q = 0..3 at m = c
+            f32x4acc v = {0, 0, 0, 0};
+            if (R0 + k < a.n) v = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)(R0 + k) * a.stride + R0 + 4 * c);
+            Ct[k][0][c] = v[0]; Ct[k][1][c] = v[1]; Ct[k][2][c] = v[2]; Ct[k][3][c] = v[3];
         }
-        __syncthreads();
     }
-    unsigned long long xw = a.XT[(size_t)b * a.Rp + r];
-    unsigned long long accepted = 0;
+    __syncthreads();
+    const unsigned long long xw = a.XT[(size_t)b * a.Rp + r];
+    unsigned long long accepted = 0, word = 0;
     bool any = false;
     if (force) {
         // field (re)initialisation: the "flips" are the set bits (f = diag + sum of the rows with x = 1)
-#pragma unroll 8
-        for (int k = 0; k < kXgB; ++k) {
-            const float sk = ((xw >> k) & 1ull) ? 1.0f : 0.0f;
-            Sj[(size_t)k * a.Rp + r] = sk;
-        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) Sj[(size_t)(q + 4 * m) * a.Rp + r] = ((xw >> (q + 4 * m)) & 1ull) ? 1.0f : 0.0f;
         any = xw != 0ull;
     } else {
-        float t[kXgB], th[kXgB];
+        float t[16], th[16];
 #pragma unroll
-        for (int k = 0; k < kXgB; ++k) {
-            t[k] = j == 0 ? a.F[fidx(a, R0 + k, r)] : a.Tm[tmidx(j - 1, k, r)];
-            th[k] = a.TH[((size_t)j * 64 + k) * a.Rp + r];
+        for (int m = 0; m < 16; ++m) {
+            t[m] = j == 0 ? a.F[fidx(a, R0 + q + 4 * m, r)] : a.Tm[tmidx(j - 1, q + 4 * m, r)];
+            th[m] = a.TH[((size_t)j * 64 + q + 4 * m) * a.Rp + r];
         }
         static_for<0, kXgB>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
+            constexpr int mk = k >> 2, qk = k & 3;
             const bool xk = ((xw >> k) & 1ull) != 0ull;
-            const float dE = xk ? -t[k] : t[k];
-            const bool acc = dE < th[k];
-            const float sk = acc ? (xk ? -1.0f : 1.0f) : 0.0f;
-            Sj[(size_t)k * a.Rp + r] = sk;
-            if (acc) { xw ^= 1ull << k; ++accepted; }
-            if (__ballot(acc) != 0ull) {                       // (wave-uniform: nobody flipped row k -> nothing to add)
+            const float dE = xk ? -t[mk] : t[mk];
+            const bool acc = (q == qk) && dE < th[mk];                    // the lane that holds row k
+            const float so = acc ? (xk ? -1.0f : 1.0f) : 0.0f;
+            const float sk = xg_quad_bcast<qk>(so);
+            if (q == qk) Sj[(size_t)k * a.Rp + r] = so;
+            if (acc) { word |= 1ull << k; ++accepted; }
+            if (__ballot(acc) != 0ull) {                                  // (wave-uniform: nobody flipped row k)
 #pragma unroll
-                for (int jj = k + 1; jj < kXgB; ++jj) t[jj] = __fmaf_rn(C[k][jj], sk, t[jj]);
+                for (int g4 = mk >> 2; g4 < 4; ++g4) {
+                    const f32x4acc c4 = *reinterpret_cast<const f32x4acc *>(&Ct[k][q][4 * g4]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[4 * g4 + i] = __fmaf_rn(c4[i], sk, t[4 * g4 + i]);
+                }
                 any = any || acc;
             }
         });
-        a.XT[(size_t)b * a.Rp + r] = xw;
+        // the quad's accepted rows -> the replica's state word
+        unsigned int lo = (unsigned int)word, hi = (unsigned int)(word >> 32);
+        lo |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, false);
+        hi |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, false);
+        lo |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, false);
+        hi |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xf, 0xf, false);
+        if (q == 0) a.XT[(size_t)b * a.Rp + r] = xw ^ (((unsigned long long)hi << 32) | lo);
     }
-    const unsigned long long anyb = __ballot(any);
-    if (lane == 0) a.flags[((size_t)par * 4 + j) * (a.Rp / kXgReps) + (r >> 6)] = anyb != 0ull ? 1u : 0u;
+    if (__ballot(any) != 0ull && lane == 0) atomicOr(&any_s, 1);
+    __syncthreads();
+    if (tid == 0) a.flags[((size_t)par * 4 + j) * (a.Rp / kXgReps) + blockIdx.x] = any_s ? 1u : 0u;
     if (!force) {
         // accepted flips of this wavefront -> stats[1]
         unsigned long long tot = accepted;
@@ -347,7 +368,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
         HIP_TRY(hipMemsetAsync(a.XT, 0, (size_t)a.nblocks * a.Rp * 8, st));     // (replicas past R: no bits)
         hipLaunchKernelGGL(k_xg_init_state, dim3(a.R, (a.nblocks + 3) / 4), dim3(64), 0, st, a);
     }
-    const dim3 gdiag(a.Rp / 256), gpanel(a.Rp / kXgReps, a.ncols / kXgCols);
+    const dim3 gdiag(a.Rp / 64), gpanel(a.Rp / kXgReps, a.ncols / kXgCols);
     const dim3 gthr((a.Rp + 255) / 256, 64);
     const dim3 gmini(a.Rp / kXgReps, 1);
     // Each stream gets its own compute units: the chain's kernels are small (4 .. 16 workgroups) and latency-critical,
