@@ -87,7 +87,13 @@ int mi_sa_problem_destroy(mi_sa_problem *p);
 int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases, int *device);
 
 /* Tuning switches that never change results: "pace" (default 1) holds the replicas of one XCD together
- * at sweep boundaries so that their Q-row reads share that XCD's L2.
+ * at sweep boundaries so that their Q-row reads share that XCD's L2.  Kernel choice (all kernels of a model
+ * run the same chain): "variant" (dense, n <= 4096: 0 auto, 1 wave per replica, 2 workgroup + LDS ring, 3 MFMA,
+ * 4 scheduled), "mfma_permille" (default 600: chunks of a long dense run that accept at least this share go to
+ * the MFMA kernel; 0 = never), "chunk_sweeps" (32), "k2_pair" (structured binary: 0 auto, 1 two replicas per
+ * wavefront, 2 one), "xl_batched" (dense, n > 4096: 0 auto = all replicas together on the matrix cores from 256
+ * replicas up, 1 always, 2 a workgroup per replica), "xl_chunk" (8) / "xl_cold_permille" (20): that batched kernel
+ * hands a cooling run over to the per-replica kernel when a chunk of sweeps accepted less than this share.
  * One MODEL switch: "min_cluster_size" (Potts problems, default 0) -- every cluster keeps at least that many
  * members: a move out of a cluster holding exactly that many is rejected whatever its energy change.  This
  * is the `sum_i v[i][j] >= 20` constraint of the reference's CQM (CQM_clustering.py:46-48) as a hard
