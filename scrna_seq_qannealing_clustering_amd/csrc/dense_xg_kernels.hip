@@ -35,7 +35,8 @@ typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
 constexpr int kXgB = 64;                 // rows per block = variables per slot of the RNG addressing
 constexpr int kXgCols = 256;             // columns per PANEL workgroup (4 waves x 64)
-constexpr int kXgReps = 64;              // replicas per PANEL workgroup (= one flag word, one DIAG wavefront)
+constexpr int kXgReps = 64;              // replicas per PANEL workgroup (= one flag word)
+constexpr int kXgGrp = 8;                // blocks per group: F is read and written once per 64 * kXgGrp rows
 
 struct XgArgs {
     const float *Q2;        // n rows x stride floats (zero diagonal, zero padding)
@@ -44,10 +45,10 @@ struct XgArgs {
     float *F;               // cached fields, [Rp / 64][ncols][64]: the 64 replicas of a PANEL workgroup contiguous per
                             // column, so that its 256 x 64 tile is ONE 64 KB run of memory (see fidx)
     unsigned long long *XT; // [nblocks][Rp] state bits of a block, bit k = x of variable 64 b + k
-    float *S;               // [2][4][64][Rp] signs of the four blocks of a group (two groups in flight: parity)
-    float *Tm;              // [Rp / 64][3][64][64] fields of the group's blocks 1..3 with the earlier blocks' rows applied (tmidx)
-    float *TH;              // [4][64][Rp] thresholds of four consecutive blocks
-    unsigned int *flags;    // [2][4][Rp / 64]: block j of the group flipped something in these 64 replicas
+    float *S;               // [2][kXgGrp][64][Rp] signs of the blocks of a group (two groups in flight: parity)
+    float *Tm;              // [Rp / 64][kXgGrp - 1][64][64] fields of the group's later blocks with the earlier blocks' rows applied
+    float *TH;              // [kXgGrp][64][Rp] thresholds of the group's blocks
+    unsigned int *flags;    // [2][kXgGrp][Rp / 64]: block j of the group flipped something in these 64 replicas
     const float *temps;
     const uint8_t *init;    // nullable, R x n
     uint8_t *states;        // R x n
@@ -66,7 +67,7 @@ __device__ __forceinline__ size_t fidx(const XgArgs &a, int col, int r)
 
 __device__ __forceinline__ size_t tmidx(int slot, int col, int r)
 {
-    return (((size_t)(r >> 6) * 3 + slot) * 64 + col) * 64 + (r & 63);
+    return (((size_t)(r >> 6) * (kXgGrp - 1) + slot) * 64 + col) * 64 + (r & 63);
 }
 
 // ---- state bits: XT[b][r] from the given initial states or the chain's own random start (tag 1) ----
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) k_xg_fill_fields(XgArgs a)
 }
 
 // thresholds of blocks 4 tg .. 4 tg + 3 for sweep s: TH[c][lane][r] = -ln(u) * T   (-inf: no such variable / replica)
-__global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_t sweep, int s_local)
+__global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_t sweep, int s_local, int slot0)
 {
     const int r = blockIdx.x * 256 + threadIdx.x, lane = blockIdx.y;
     if (r >= a.Rp) return;
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_
             if ((4 * tg + c) * 64 + lane < a.n) th[c] = neglog_u(w[c]) * T;
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a.TH[((size_t)c * 64 + lane) * a.Rp + r] = th[c];
+    for (int c = 0; c < 4; ++c) a.TH[((size_t)(slot0 + c) * 64 + lane) * a.Rp + r] = th[c];
 }
 
 // ---- DIAG(b): FOUR lanes per replica (a quad), 64 replicas per workgroup.  Lane q of a quad holds the fields of the
@@ -129,8 +130,8 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force, int
     __shared__ int any_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = tid & 3, r = blockIdx.x * 64 + (tid >> 2);
-    const int R0 = b * kXgB, j = b & 3;
-    float *Sj = a.S + ((size_t)par * 4 + j) * kXgB * a.Rp;
+    const int R0 = b * kXgB, j = b % kXgGrp;
+    float *Sj = a.S + ((size_t)par * kXgGrp + j) * kXgB * a.Rp;
     if (tid == 0) any_s = 0;
     if (!force) {
         for (int e = tid; e < kXgB * kXgB / 4; e += 256) {
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force, int
     }
     if (__ballot(any) != 0ull && lane == 0) atomicOr(&any_s, 1);
     __syncthreads();
-    if (tid == 0) a.flags[((size_t)par * 4 + j) * (a.Rp / kXgReps) + blockIdx.x] = any_s ? 1u : 0u;
+    if (tid == 0) a.flags[((size_t)par * kXgGrp + j) * (a.Rp / kXgReps) + blockIdx.x] = any_s ? 1u : 0u;
     if (!force) {
         // accepted flips of this wavefront -> stats[1]
         unsigned long long tot = accepted;
@@ -212,24 +213,25 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     constexpr int CR = 16;                                    // rows of Q2 per chunk in LDS (the next chunk waits in registers)
     __shared__ __attribute__((aligned(16))) float Apan[CR][AS];
     __shared__ __attribute__((aligned(16))) float Ssl[kXgB][SS];
-    const int rx = blockIdx.x, cy = cy_only >= 0 ? cy_only : (int)blockIdx.y, ranges = a.Rp / kXgReps;
-    if (!MINI && cy == cy_skip) return;
+    const int rx = blockIdx.x, cy = cy_only >= 0 ? cy_only + (int)blockIdx.y : (int)blockIdx.y, ranges = a.Rp / kXgReps;
+    if (!MINI && cy_skip >= 0 && cy >= cy_skip && cy < cy_skip + kXgGrp / 4) return;
+    const int yy = MINI ? (int)blockIdx.y : 0;                // MINI: which four of the later blocks
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int rep0 = rx * kXgReps;
     const int jb0 = MINI ? j : 0, jb1 = MINI ? j + 1 : nbg;   // row blocks of the group this pass applies
-    const int col0 = MINI ? (4 * g + j + 1) * kXgB : cy * kXgCols;
+    const int col0 = MINI ? (kXgGrp * g + j + 1 + 4 * yy) * kXgB : cy * kXgCols;
     unsigned int live = 0;                                    // bit jj: block jj flipped a row in these 64 replicas
-    for (int jj = jb0; jj < jb1; ++jj) live |= (a.flags[((size_t)par * 4 + jj) * ranges + rx] != 0u ? 1u : 0u) << jj;
+    for (int jj = jb0; jj < jb1; ++jj) live |= (a.flags[((size_t)par * kXgGrp + jj) * ranges + rx] != 0u ? 1u : 0u) << jj;
     if (live == 0u && !(MINI && j == 0)) return;              // (the first MINI of a group also COPIES F into Tm)
-    const bool wave_on = !MINI || wave < nbg - 1 - j;         // MINI: one wave per later block of the group
+    const bool wave_on = !MINI || 4 * yy + wave < nbg - 1 - j;   // MINI: one wave per later block of the group
 
     f32x4acc pre[CR / 4];
     auto fetch_chunk = [&](int jj, int c) {                   // rows 16 c .. 16 c + 15 of block 4 g + jj, columns col0 ..
 #pragma unroll
         for (int i = 0; i < CR / 4; ++i) {
-            const int row = (4 * g + jj) * kXgB + CR * c + 4 * i + (tid >> 6), col = col0 + 4 * (tid & 63);
+            const int row = (kXgGrp * g + jj) * kXgB + CR * c + 4 * i + (tid >> 6), col = col0 + 4 * (tid & 63);
             pre[i] = f32x4acc{0, 0, 0, 0};
             if (row < a.n && (size_t)col < a.stride) pre[i] = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)row * a.stride + col);
         }
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
         const int r = rep0 + 16 * rt + 4 * lq;
         if (MINI) {
             if (!dst && j == 0) return a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, r);
-            return a.Tm + tmidx(j + wave, 16 * ct + lr, r);
+            return a.Tm + tmidx(j + 4 * yy + wave, 16 * ct + lr, r);
         }
         return a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, r);
     };
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
         for (int e = tid; e < kXgB * kXgReps / 4; e += 256) {
             const int k = e >> 4, j4 = (e & 15) * 4;
             *reinterpret_cast<f32x4acc *>(&Ssl[k][j4]) =
-                *reinterpret_cast<const f32x4acc *>(a.S + (((size_t)par * 4 + jj) * kXgB + k) * a.Rp + rep0 + j4);
+                *reinterpret_cast<const f32x4acc *>(a.S + (((size_t)par * kXgGrp + jj) * kXgB + k) * a.Rp + rep0 + j4);
         }
 #pragma unroll 1
         for (int c = 0; c < kXgB / CR; ++c) {
@@ -316,7 +318,8 @@ size_t mi_dense_xg_workspace_bytes(int n, int R)
 {
     const size_t Rp = ((size_t)R + 255) / 256 * 256, ncols = ((size_t)n + kXgCols - 1) / kXgCols * kXgCols;
     const size_t nblocks = ((size_t)n + kXgB - 1) / kXgB;
-    return ncols * Rp * 4 + nblocks * Rp * 8 + 8 * (size_t)kXgB * Rp * 4 + 3 * 64 * Rp * 4 + 4 * 64 * Rp * 4 + 8 * (Rp / 64) * 4 + 256;
+    return ncols * Rp * 4 + nblocks * Rp * 8 + 2 * kXgGrp * (size_t)kXgB * Rp * 4 + (kXgGrp - 1) * 64 * Rp * 4 + kXgGrp * 64 * Rp * 4 +
+           2 * kXgGrp * (Rp / 64) * 4 + 256;
 }
 
 // The whole run: (re)initialisation passes and sweeps as K1x orders them; two launches per block of 64 rows.
@@ -355,14 +358,14 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     char *w = static_cast<char *>(workspace);
     a.F = reinterpret_cast<float *>(w);                      w += (size_t)a.ncols * a.Rp * 4;
     a.XT = reinterpret_cast<unsigned long long *>(w);        w += (size_t)a.nblocks * a.Rp * 8;
-    a.S = reinterpret_cast<float *>(w);                      w += 8 * (size_t)kXgB * a.Rp * 4;
-    a.Tm = reinterpret_cast<float *>(w);                     w += 3 * (size_t)64 * a.Rp * 4;
-    a.TH = reinterpret_cast<float *>(w);                     w += (size_t)4 * 64 * a.Rp * 4;
+    a.S = reinterpret_cast<float *>(w);                      w += 2 * kXgGrp * (size_t)kXgB * a.Rp * 4;
+    a.Tm = reinterpret_cast<float *>(w);                     w += (kXgGrp - 1) * (size_t)64 * a.Rp * 4;
+    a.TH = reinterpret_cast<float *>(w);                     w += (size_t)kXgGrp * 64 * a.Rp * 4;
     a.flags = reinterpret_cast<unsigned int *>(w);
     a.temps = x.temps; a.init = x.init; a.states = x.states; a.energy = x.energy; a.stats = x.stats; a.offset = x.offset;
     a.replica_offset = x.replica_offset; a.seed_lo = x.seed_lo; a.seed_hi = x.seed_hi;
     a.temps_per_replica = x.temps_per_replica;
-    note_kernel("k_xg_diag + k_xg_panel (K1g, %d blocks of 64 rows in groups of 4)", a.nblocks);
+    note_kernel("k_xg_diag + k_xg_panel (K1g, %d blocks of 64 rows in groups of %d)", a.nblocks, kXgGrp);
 
     if (begin) {
         HIP_TRY(hipMemsetAsync(a.XT, 0, (size_t)a.nblocks * a.Rp * 8, st));     // (replicas past R: no bits)
@@ -370,7 +373,6 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     }
     const dim3 gdiag(a.Rp / 64), gpanel(a.Rp / kXgReps, a.ncols / kXgCols);
     const dim3 gthr((a.Rp + 255) / 256, 64);
-    const dim3 gmini(a.Rp / kXgReps, 1);
     // Each stream gets its own compute units: the chain's kernels are small (4 .. 16 workgroups) and latency-critical,
     // and behind a full pass that keeps every CU filled from its 3000-workgroup grid they were not scheduled until
     // the pass had drained (measured: a 23 us DIAG took 234 us) -- 8 of the 256 CUs are set aside for them.
@@ -411,7 +413,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
         if (int rc = sync.event(&evS[i])) return rc;
         if (int rc = sync.event(&evP[i])) return rc;
     }
-    const int ngroups = (a.nblocks + 3) / 4;
+    const int ngroups = (a.nblocks + kXgGrp - 1) / kXgGrp;
     long G = 0;                                               // running group count
     // the list of passes: (force, sweep index)
     struct Pass { int force; uint32_t sweep; int s_local; };
@@ -436,7 +438,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
             hipLaunchKernelGGL(k_xg_fill_fields, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, sa, a);
         }
         for (int g = 0; g < ngroups; ++g, ++G) {
-            const int nbg = a.nblocks - 4 * g < 4 ? a.nblocks - 4 * g : 4;
+            const int nbg = a.nblocks - kXgGrp * g < kXgGrp ? a.nblocks - kXgGrp * g : kXgGrp;
             const int par = (int)(G & 1);
             const bool last_of_pass = g + 1 == ngroups;
             const bool has_next = !last_of_pass || pi + 1 < passes.size();
@@ -445,11 +447,13 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
             if (G >= 2) HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 2) & 3], 0));        // S / flags of this parity are free
             if (!ps.force && G >= 1 && !split_prev)                                   // its own columns of F are final: the
                 HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 1) & 3], 0));                 // previous full pass (or its first part, on B)
-            if (!ps.force) hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, sb, a, g, ps.sweep, ps.s_local);
+            if (!ps.force)
+                for (int h = 0; 4 * h < nbg; ++h)
+                    hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, sb, a, g * (kXgGrp / 4) + h, ps.sweep, ps.s_local, 4 * h);
             for (int j = 0; j < nbg; ++j) {
-                hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, sb, a, 4 * g + j, ps.force, par);
+                hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, sb, a, kXgGrp * g + j, ps.force, par);
                 if (!ps.force && j + 1 < nbg)
-                    hipLaunchKernelGGL(k_xg_panel<true>, gmini, dim3(256), 0, sb, a, g, nbg, j, par, -1, -1);
+                    hipLaunchKernelGGL(k_xg_panel<true>, dim3(a.Rp / kXgReps, (nbg - 1 - j + 3) / 4), dim3(256), 0, sb, a, g, nbg, j, par, -1, -1);
             }
             HIP_TRY(hipEventRecord(evS[G & 3], sb));
             // ---- the group's full pass over F: the next group's own 256 columns on B (in front of that group's chain; they
@@ -459,8 +463,10 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
             if (split_prev) {
                 const int gn = last_of_pass ? 0 : g + 1;
                 if (G >= 1) HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 1) & 3], 0));
-                hipLaunchKernelGGL(k_xg_panel<false>, gmini, dim3(256), 0, sb, a, g, nbg, 0, par, gn, -1);
-                hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, gn);
+                const int cyn = gn * (kXgGrp / 4);                 // the next group's columns: kXgGrp / 4 workgroup ranges
+                const int ncy = (a.ncols / kXgCols - cyn) < kXgGrp / 4 ? (a.ncols / kXgCols - cyn) : kXgGrp / 4;
+                hipLaunchKernelGGL(k_xg_panel<false>, dim3(a.Rp / kXgReps, ncy), dim3(256), 0, sb, a, g, nbg, 0, par, cyn, -1);
+                hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, cyn);
             } else {
                 hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, -1);
             }
