@@ -248,10 +248,10 @@ def dense_xl_50k(rank_device, n=50000, replicas=1024, sweeps=4):
     """BASELINE config 4 in its literal form: a synthetic 50 000-cell SNN graph built on the GPU (snn.build_snn), the
     clustering_bqm QUBO as a dense fp32 matrix (10.6 GB resident in HBM), one GPU's share of the replicas (8192 / 8), the
     first `sweeps` sweeps of the 1000-step schedule (the hot end: > 99 % of the proposals are accepted).  Kernel K1g:
-    all replicas walk the rows together, 64 rows per DIAG, the row updates of a group of 256 rows as one GEMM-shaped
+    all replicas walk the rows together, 64 rows per DIAG, the row updates of a group of 512 rows as one GEMM-shaped
     pass over F[column][replica] on the matrix cores.  `mfma_roofline` = its flop (2 x rows x columns x replicas per
     pass, the field initialisation pass included) against the f32-input MFMA peak; `field_traffic` = the
-    read-modify-write of F per group of 256 rows; `hbm_side` = what rocprofv3 FETCH_SIZE x 2 saw on this shape
+    read-modify-write of F per group of 512 rows; `hbm_side` = what rocprofv3 FETCH_SIZE x 2 saw on this shape
     (profiles/r02_dense50k.json).  K1x (a workgroup per replica, one Q row per accepted flip) is what batches below
     256 replicas run: 3.5e7 updates/s on this model."""
     from scrna_seq_qannealing_clustering_amd import models, snn
@@ -279,7 +279,7 @@ def dense_xl_50k(rank_device, n=50000, replicas=1024, sweeps=4):
     nblocks, ncols, rp = (n + 63) // 64, ((n + 255) // 256) * 256, ((replicas + 255) // 256) * 256
     passes = sweeps + 1                                                           # + the field initialisation pass
     flop = 2.0 * (64 * nblocks) * ncols * rp * passes
-    f_bytes = 8.0 * ncols * rp * ((nblocks + 3) // 4) * passes
+    f_bytes = 8.0 * ncols * rp * ((nblocks + 7) // 8) * passes
     rec = _profile_json("r02_dense50k.json")
     hbm = None
     if rec and rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("n") == n:
@@ -295,7 +295,7 @@ def dense_xl_50k(rank_device, n=50000, replicas=1024, sweeps=4):
                               "model": "2 x (64 x blocks) rows x padded columns x padded replicas per pass, all rows, "
                                        "accepted or not (v_mfma_f32_16x16x4_f32 chained in row order: bit-exact)"},
             "field_traffic": {"GBps": f_bytes / (ms * 1e-3) / 1e9,
-                              "note": "read + write of the cached fields F[column][replica] once per group of 256 rows"},
+                              "note": "read + write of the cached fields F[column][replica] once per group of 512 rows"},
             "hbm_side": hbm,
             "host_build_s": t_build, "upload_s": t_upload, "best_energy": float(en.min())}
 
