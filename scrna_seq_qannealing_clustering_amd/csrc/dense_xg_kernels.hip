@@ -213,9 +213,19 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     constexpr int CR = 16;                                    // rows of Q2 per chunk in LDS (the next chunk waits in registers)
     __shared__ __attribute__((aligned(16))) float Apan[CR][AS];
     __shared__ __attribute__((aligned(16))) float Ssl[kXgB][SS];
-    const int rx = blockIdx.x, cy = cy_only >= 0 ? cy_only + (int)blockIdx.y : (int)blockIdx.y, ranges = a.Rp / kXgReps;
+    // workgroup -> tile, XCD-aware: consecutive workgroup ids go round the 8 XCDs, each with an L2 of its own.  The replica
+    // ranges of one column range read the same rows of Q2: they get consecutive ids on ONE XCD (a contiguous chunk of
+    // the tile list per XCD, bijective for any grid), so Q2 leaves HBM once per pass, not once per XCD.
+    const int ranges = a.Rp / kXgReps;
+    int tile = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    if (!MINI) {
+        const int nwg = (int)(gridDim.x * gridDim.y), qq = nwg / 8, rr = nwg % 8, xcd = tile % 8;
+        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + tile / 8;
+    }
+    const int rx = tile % (int)gridDim.x, ty = tile / (int)gridDim.x;
+    const int cy = cy_only >= 0 ? cy_only + ty : ty;
     if (!MINI && cy_skip >= 0 && cy >= cy_skip && cy < cy_skip + kXgGrp / 4) return;
-    const int yy = MINI ? (int)blockIdx.y : 0;                // MINI: which four of the later blocks
+    const int yy = MINI ? ty : 0;                             // MINI: which four of the later blocks
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
