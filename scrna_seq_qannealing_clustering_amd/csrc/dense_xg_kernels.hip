@@ -18,7 +18,7 @@
 //             are simply dropped.
 // A Q row is read once per sweep for all replicas (10.6 GB per sweep at n = 50 000 instead of 213 KB per accepted
 // flip and replica); what the pass costs is the read-modify-write of F (n_pad x R x 8 B per block) and
-// 2 * 64 * n_pad * R flop per block on the matrix pipe.  The read-modify-write is paid once per GROUP of four
+// 2 * 64 * n_pad * R flop per block on the matrix pipe.  The read-modify-write is paid once per GROUP of eight
 // blocks: inside a group the later blocks' own columns get the earlier blocks' rows by small passes into a side
 // buffer (Tm), so that their DIAGs can run before the group's full pass.  The chain of the NEXT group runs on a second
 // stream with 8 compute units of its own beside the current group's full pass (events order them; see the launcher).
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_
 // block's columns q, 4 + q, ..., 60 + q; step k decides row k in lane q = k % 4, the sign goes round the quad by DPP,
 // every lane applies the coupling row to its 16 fields (those of rows already decided are dead and may take
 // garbage) -- a quarter of the fmaf chain per lane of the one-thread-per-replica form (25 -> 10 us per block).
-// j = b % 4: position in its group of four blocks -- block 0 reads its fields from F, the others from Tm (F plus the
+// j = b % kXgGrp: position in its group of blocks -- block 0 reads its fields from F, the others from Tm (F plus the
 // rows of the group's earlier blocks, k_xg_panel<true>) ----
 template <int QK>
 __device__ __forceinline__ float xg_quad_bcast(float v)
@@ -199,10 +199,10 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force, int
 
 // ---- PANEL: fields (+)= sum over rows of Q2[row][col] * S[row][r], the rows in order, as chained MFMAs ----
 // workgroup = 256 columns x 64 replicas, wave w = 64 columns: 4 x 4 tiles, C[i = replica][j = column].
-//   MINI = false: the whole group g (blocks 4 g .. 4 g + nbg - 1, 64 nbg rows) onto ALL columns of F -- F is read and
+//   MINI = false: the whole group g (blocks G g .. G g + nbg - 1, G = kXgGrp; 64 nbg rows) onto ALL columns of F -- F is read and
 //                 written once per 256 rows, which is what this pass costs besides the MFMAs;
-//   MINI = true:  the rows of block 4 g + j alone onto the columns of the group's LATER blocks (wave w: block
-//                 4 g + j + 1 + w), into Tm -- the fields the next DIAGs of the group decide on.  F itself is
+//   MINI = true:  the rows of block G g + j alone onto the columns of the group's LATER blocks (workgroup y, wave w: block
+//                 G g + j + 1 + 4 y + w), into Tm -- the fields the next DIAGs of the group decide on.  F itself is
 //                 untouched until the group's full pass, which applies the same rows in the same order.
 // The full pass of a group is launched in two parts: first the 256 columns that are the NEXT group's own (cy_only), then
 // the rest (cy_skip) -- the next group's DIAGs need only the first part and run beside the second (dense_xg host loop).
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     const bool wave_on = !MINI || 4 * yy + wave < nbg - 1 - j;   // MINI: one wave per later block of the group
 
     f32x4acc pre[CR / 4];
-    auto fetch_chunk = [&](int jj, int c) {                   // rows 16 c .. 16 c + 15 of block 4 g + jj, columns col0 ..
+    auto fetch_chunk = [&](int jj, int c) {                   // rows 16 c .. 16 c + 15 of block kXgGrp g + jj, columns col0 ..
 #pragma unroll
         for (int i = 0; i < CR / 4; ++i) {
             const int row = (kXgGrp * g + jj) * kXgB + CR * c + 4 * i + (tid >> 6), col = col0 + 4 * (tid & 63);
