@@ -258,6 +258,27 @@ def test_error_behaviour():
         p.anneal(2, [1.0], 1, initial_states=np.zeros((3, 4)))
     p.close()
     assert b"" == b"" and lib.mi_last_error() is not None
+    # holes of a padded layout: only positions without couplings, only Potts problems (a binary CSR model marks its
+    # holes by lin = +inf); planner arguments are checked before anything is touched
+    rowptr, col = np.array([0, 1, 2, 2], dtype=np.int32), np.array([1, 0], dtype=np.int32)
+    val = np.ones(2, dtype=np.float32)
+    with Problem.potts_csr(rowptr, col, val, 0.1, 3, 2) as pp:
+        bad = np.array([1, 0, 0], dtype=np.uint8)                                  # variable 0 has a coupling
+        assert lib.mi_sa_problem_set_absent(pp._h, bad.ctypes.data_as(C.POINTER(C.c_uint8))) == -1
+        ok = np.array([0, 0, 1], dtype=np.uint8)
+        _lib.check(lib.mi_sa_problem_set_absent(pp._h, ok.ctypes.data_as(C.POINTER(C.c_uint8))))
+        pp.anneal(4, np.geomspace(0.1, 5.0, 6), 3)
+        lab, _, info = pp.fetch()
+        assert not lab[:, 2].any() and info["proposals"] == 4 * 6 * 3              # (the engine counts the caller's n)
+    with Problem.csr_rank1(rowptr, col, val, np.zeros(3, dtype=np.float32), 0.0) as pb:
+        assert lib.mi_sa_problem_set_absent(pb._h, ok.ctypes.data_as(C.POINTER(C.c_uint8))) == -5
+    pos = np.zeros(3, dtype=np.int64)
+    ns = C.c_int(0)
+    assert lib.mi_sa_plan_slot_layout(rowptr.ctypes.data_as(C.POINTER(C.c_int32)), col.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      0, 64, 8, pos.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(ns), None) == -1
+    badcol = np.array([7, 0], dtype=np.int32)
+    assert lib.mi_sa_plan_slot_layout(rowptr.ctypes.data_as(C.POINTER(C.c_int32)), badcol.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      3, 64, 8, pos.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(ns), None) == -1
 
 
 def test_full_size_properties_pbmc3k_surrogate():
