@@ -21,6 +21,9 @@ ap.add_argument("--n", type=int, default=50000)
 ap.add_argument("--replicas", type=int, default=256)
 ap.add_argument("--sweeps", type=int, default=2)
 ap.add_argument("--start", type=int, default=450, help="first beta of the 1000-step schedule to use")
+ap.add_argument("--stride", type=int, default=1, help="take every stride-th beta (a short run over the whole range)")
+ap.add_argument("--cold", type=int, default=-1, help="xl_cold_permille option (-1: the default)")
+ap.add_argument("--batched", type=int, default=0, help="xl_batched option: 0 auto, 1 K1g, 2 K1x")
 a = ap.parse_args()
 n = a.n
 rng = np.random.RandomState(1)
@@ -34,10 +37,13 @@ rows = np.repeat(np.arange(n), np.diff(m.rowptr))
 Qs[rows, m.col] += (m.val / 2.0).astype(np.float32)
 Qs[np.arange(n), np.arange(n)] = m.lin.astype(np.float32)
 t_build = time.perf_counter() - t0
-betas = models.make_beta_schedule(1000, models.default_beta_range(m))[a.start:a.start + a.sweeps]   # temperatures from the middle of the schedule
+betas = models.make_beta_schedule(1000, models.default_beta_range(m))[a.start::a.stride][:a.sweeps]   # temperatures from the middle of the schedule
 t0 = time.perf_counter()
 with Problem.dense(Qs) as p:
     t_upload = time.perf_counter() - t0
+    p.set_option("xl_batched", a.batched)
+    if a.cold >= 0:
+        p.set_option("xl_cold_permille", a.cold)
     p.anneal(a.replicas, betas, 1234)
     ms = p.kernel_ms()
     p_kernel_name = p.kernel_name()

@@ -23,7 +23,8 @@
 // buffer (Tm), so that their DIAGs can run before the group's full pass.  The chain of the NEXT group runs on a second
 // stream with 8 compute units of its own beside the current group's full pass (events order them; see the launcher).
 // Thresholds for four blocks at a time (one Philox block serves four 64-variable slots).
-// Used for R >= 256 replicas; K1x keeps the small batches and the cold end of a cooling run (mi_sa.hip).
+// Used for R >= 256 replicas or n >= 16384; K1x keeps small batches of small problems and the cold end of a cooling
+// run (mi_sa.hip).
 #include "mi_sa_device.h"
 #include <cstdlib>
 #include <vector>

@@ -166,7 +166,7 @@ struct mi_sa_problem {
     float *d_Q2xl = nullptr, *d_diagxl = nullptr;   // K1x (n > 4096): padded rows of 2*Qs, diagonal
     void *d_xg = nullptr;                    // K1g workspace (fields of all replicas, state words, signs, thresholds)
     size_t xg_bytes = 0;
-    int opt_xl_batched = 0;                  // n > 4096: 0 auto (K1g for >= 256 replicas), 1 always K1g, 2 always K1x
+    int opt_xl_batched = 0;                  // n > 4096: 0 auto (K1g for >= 256 replicas or n >= 16384), 1 always K1g, 2 always K1x
     int opt_xl_chunk = 8;                    // K1g: sweeps per chunk of a cooling run (the hand-over to K1x is decided per chunk)
     int opt_xl_cold_permille = 20;           // hand the rest of the run to K1x when a chunk accepted less than this share (0 = never)
     int xl_chunks = 0;
@@ -857,7 +857,11 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
         p->last_launches = 1;
-        const bool batched = p->opt_xl_batched == 1 || (p->opt_xl_batched == 0 && R >= 256);
+        // K1x pays per accepted flip (a barrier and the L2 latency of one Q row: ~1 us up to n = 8192, 3 us at 20 000,
+        // 8 us at 50 000) and runs 256 replicas at a time; K1g pays ~25 us per 64 rows whatever the replica count
+        // below 256.  Measured (profiles/r02_xl_crossover.json): K1x wins at n <= 8192 with <= 64 replicas (2-3x),
+        // K1g from n = 20 000 at any count (1.1-2x over a whole schedule, 9x on its hot part at 50 000).
+        const bool batched = p->opt_xl_batched == 1 || (p->opt_xl_batched == 0 && (R >= 256 || p->n >= 16384));
         if (batched) {
             const size_t need = mi_dense_xg_workspace_bytes(p->n, R);
             if (need > p->xg_bytes) {

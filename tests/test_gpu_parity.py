@@ -360,7 +360,7 @@ def test_dense_beyond_4096_variables_workgroup_per_replica(n, R, sweeps):
         ost, oen, ostats = so.sa_dense_philox(Qs, R, betas, 11, replica_offset=5, **kw)
         with Problem.dense(Qs) as p:
             # 2 = K1x (a workgroup per replica); 1 = K1g (all replicas together, 64 rows per GEMM-shaped pass on the matrix
-            # cores -- what runs of >= 256 replicas take by default)
+            # cores -- what runs of >= 256 replicas, or of n >= 16384, take by default)
             for mode, name in ((2, "k_anneal_dense_xl"), (1, "k_xg_diag + k_xg_panel")):
                 p.set_option("xl_batched", mode)
                 p.anneal(R, betas, 11, replica_offset=5, initial_states=kw.get("init"),
@@ -457,6 +457,7 @@ def test_full_size_properties_config4_dense_50k():
     Qs[np.arange(n), np.arange(n)] = m.lin.astype(np.float32)
     betas = models.make_beta_schedule(1000, models.default_beta_range(m))[620:622]
     with Problem.dense(Qs) as p:
+        p.set_option("xl_batched", 2)                         # K1x: a workgroup per replica
         p.anneal(2, betas, 77, replica_offset=4094)
         st, en, info = p.fetch()
         assert p.kernel_name().startswith("k_anneal_dense_xl<13>")
