@@ -1233,17 +1233,23 @@ int mi_energy_dense_f32_ex(const float *Qs, int n, const uint8_t *X, int R, doub
     float *dQ = nullptr; uint8_t *dX = nullptr, *dXt = nullptr; double *dE = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     rc = [&]() -> int {
-        const size_t Rpad = ((size_t)R + 127) / 128 * 128;
-        HIP_TRY(hipMalloc((void **)&dQ, (size_t)n * n * sizeof(float)));
+        // the MFMA kernel reads whole 128 x 128 blocks: rows padded to n_pad floats, n_pad rows, padding zero
+        const size_t ldq = path == 2 ? ((size_t)n + 127) / 128 * 128 : (size_t)n;
+        const size_t rows = path == 2 ? ldq : (size_t)n;
+        HIP_TRY(hipMalloc((void **)&dQ, rows * ldq * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&dX, (size_t)R * n));
         HIP_TRY(hipMalloc((void **)&dE, (size_t)R * sizeof(double)));
-        if (path == 2) HIP_TRY(hipMalloc((void **)&dXt, (size_t)n * Rpad));
-        HIP_TRY(hipMemcpy(dQ, Qs, (size_t)n * n * sizeof(float), hipMemcpyHostToDevice));
+        if (path == 2) {
+            HIP_TRY(hipMalloc((void **)&dXt, mi_energy_dense_scratch_bytes(n, R)));
+            HIP_TRY(hipMemset(dQ, 0, rows * ldq * sizeof(float)));
+        }
+        HIP_TRY(hipMemcpy2D(dQ, ldq * sizeof(float), Qs, (size_t)n * sizeof(float), (size_t)n * sizeof(float), (size_t)n,
+                            hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dX, X, (size_t)R * n, hipMemcpyHostToDevice));
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, 0));
-        int r2 = mi_launch_energy_dense(dQ, n, dX, R, offset, dE, dXt, path, 0);
+        int r2 = mi_launch_energy_dense(dQ, n, (int)ldq, dX, R, offset, dE, dXt, path, 0);
         if (r2) return r2;
         HIP_TRY(hipEventRecord(e1, 0));
         HIP_TRY(hipEventSynchronize(e1));

@@ -302,7 +302,8 @@ __device__ __forceinline__ uint32_t chain_word_dev(uint32_t i, uint32_t s, uint3
 }
 
 // K4 launcher (energy_kernels.hip); all pointers are device pointers
-int mi_launch_energy_dense(const float *dQ, int n, const uint8_t *dX, int R, double offset, double *dE,
+size_t mi_energy_dense_scratch_bytes(int n, int R);
+int mi_launch_energy_dense(const float *dQ, int n, int ldq, const uint8_t *dX, int R, double offset, double *dE,
                            uint8_t *dXt, int path, hipStream_t st);
 int mi_launch_energy_dense_f64(const double *dQ, int n, const uint8_t *dX, int R, double offset, double *dE, hipStream_t st);
 
