@@ -12,6 +12,16 @@ from scrna_seq_qannealing_clustering_amd import engine  # noqa: E402
 
 m, Qs, betas, _, _ = bench.build_workload()
 X = np.random.RandomState(0).randint(0, 2, size=(4096, Qs.shape[0])).astype(np.uint8)
+if os.environ.get("K4_N"):                      # a larger random model: the steady state of the kernel (K4_N=8192 K4_R=8192)
+    n, R = int(os.environ["K4_N"]), int(os.environ.get("K4_R", "8192"))
+    rs = np.random.RandomState(3)
+    A = rs.standard_normal((n, n)).astype(np.float32)
+    Qs = np.ascontiguousarray((A + A.T) / 2)
+    X = (rs.rand(R, n) < 0.4).astype(np.uint8)
+    for _ in range(2):
+        e, ms = engine.energy_dense(Qs, X, path=2, return_ms=True)
+        print("path 2: %.3f ms  %.1f TFLOP/s (2 n^2 R flop)" % (ms, 2.0 * n * n * R / ms / 1e9), flush=True)
+    sys.exit(0)
 for path in (2, 2, 1):
     e, ms = engine.energy_dense(Qs, X, path=path, return_ms=True)
     print("path %d: %.3f ms  %.1f TFLOP/s (2 n^2 R flop)" % (path, ms, 2.0 * Qs.shape[0] ** 2 * 4096 / ms / 1e9), flush=True)

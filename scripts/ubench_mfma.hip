@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -95,8 +96,9 @@ __global__ void __launch_bounds__(256) k_mfma_lds(float *out, int chunks)
     if (s == 12345.678f) out[0] = s;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const int lds_chunks = argc > 1 ? atoi(argv[1]) : 300;
     float *out;
     CHECK(hipMalloc(&out, 64));
     hipEvent_t e0, e1;
@@ -125,7 +127,7 @@ int main()
         }
     for (int variant = 0; variant < 4; ++variant)
         for (int wgs_per_cu = 1; wgs_per_cu <= 2; ++wgs_per_cu) {
-            const int chunks = 300;
+            const int chunks = lds_chunks;
             float best = 1e30f;
             for (int rep = 0; rep < 4; ++rep) {
                 CHECK(hipEventRecord(e0, 0));
