@@ -92,7 +92,8 @@ int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases
  * 4 scheduled), "mfma_permille" (default 600: chunks of a long dense run that accept at least this share go to
  * the MFMA kernel; 0 = never), "chunk_sweeps" (32), "k2_pair" (structured binary: 0 auto, 1 two replicas per
  * wavefront, 2 one), "xl_batched" (dense, n > 4096: 0 auto = all replicas together on the matrix cores from 256
- * replicas or n = 16384 up, 1 always, 2 a workgroup per replica), "xl_chunk" (8) / "xl_cold_permille" (20): that batched kernel
+ * replicas or n = 16384 up, 1 always, 2 a workgroup per replica), "xl_chain" (0 auto = the decisions and small passes of a group of eight blocks as one launch up to 512
+ * replicas, 1 = one launch per block, 2 = fused always), "xl_chunk" (8) / "xl_cold_permille" (20): that batched kernel
  * hands a cooling run over to the per-replica kernel when a chunk of sweeps accepted less than this share.
  * One MODEL switch: "min_cluster_size" (Potts problems, default 0) -- every cluster keeps at least that many
  * members: a move out of a cluster holding exactly that many is rejected whatever its energy change.  This

@@ -23,6 +23,7 @@ ap.add_argument("--sweeps", type=int, default=2)
 ap.add_argument("--start", type=int, default=450, help="first beta of the 1000-step schedule to use")
 ap.add_argument("--stride", type=int, default=1, help="take every stride-th beta (a short run over the whole range)")
 ap.add_argument("--cold", type=int, default=-1, help="xl_cold_permille option (-1: the default)")
+ap.add_argument("--chain", type=int, default=0, help="xl_chain option: 0 auto, 1 DIAG + small pass per block, 2 fused chain kernel")
 ap.add_argument("--batched", type=int, default=0, help="xl_batched option: 0 auto, 1 K1g, 2 K1x")
 a = ap.parse_args()
 n = a.n
@@ -42,6 +43,7 @@ t0 = time.perf_counter()
 with Problem.dense(Qs) as p:
     t_upload = time.perf_counter() - t0
     p.set_option("xl_batched", a.batched)
+    p.set_option("xl_chain", a.chain)
     if a.cold >= 0:
         p.set_option("xl_cold_permille", a.cold)
     p.anneal(a.replicas, betas, 1234)

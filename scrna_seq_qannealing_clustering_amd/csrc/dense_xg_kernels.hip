@@ -198,6 +198,157 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force, int
     }
 }
 
+// ---- CHAIN(g): the whole chain of a group in ONE launch, one workgroup per 64 replicas.  The DIAGs and small passes of
+// a group never leave their replica range: the fields of the group's later blocks (7 x 64 columns x 64 replicas) live
+// in LDS instead of Tm, DIAG(j) decides on them, and the rows of block j go onto the columns of blocks j + 1 .. by
+// chained MFMAs straight out of and back into LDS (wave w: later blocks j + 1 + w, j + 5 + w; the Q2 operands of a
+// wave's first later block are loaded BEFORE the 64 sequential decisions and arrive under them).  Same arithmetic
+// in the same order as k_xg_diag + k_xg_panel<true> (tests compare the two), 15 launches and their gaps fewer per
+// group: below 256 replicas the chain IS the run time.  Signs, state words and flags go to HBM as before (the
+// group's full pass reads them); thresholds come from k_xg_thresholds. ----
+constexpr int kXgFS = 68;                // padded replica stride of the LDS fields (16-byte tile reads, 2-way at worst)
+
+__global__ void __launch_bounds__(256, 1) k_xg_chain(XgArgs a, int g, int nbg, int par)
+{
+    __shared__ __attribute__((aligned(16))) float Fo[kXgGrp - 1][kXgB][kXgFS];   // fields of blocks 1 .. of the group
+    __shared__ __attribute__((aligned(16))) float Ct[kXgB][4][16];               // Ct[k][q][m] = Q2[R0 + k][R0 + q + 4 m]
+    __shared__ __attribute__((aligned(16))) float Sl[kXgB][kXgReps + 16];         // signs of the running block
+    __shared__ int any_s[kXgGrp];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = tid & 3, rl = tid >> 2, r = blockIdx.x * 64 + rl;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ranges = a.Rp / kXgReps;
+    if (tid < kXgGrp) any_s[tid] = 0;
+    // the later blocks' fields: 64 columns x 64 replicas of a block are one 16 KB run of F
+    for (int jb = 1; jb < nbg; ++jb) {
+        const float *src = a.F + fidx(a, (kXgGrp * g + jb) * kXgB, blockIdx.x * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, col = e >> 4, r4 = (e & 15) * 4;
+            *reinterpret_cast<f32x4acc *>(&Fo[jb - 1][col][r4]) = *reinterpret_cast<const f32x4acc *>(src + (size_t)col * 64 + r4);
+        }
+    }
+    unsigned long long accepted = 0;
+    for (int j = 0; j < nbg; ++j) {
+        const int b = kXgGrp * g + j, R0 = b * kXgB;
+        float *Sj = a.S + ((size_t)par * kXgGrp + j) * kXgB * a.Rp;
+        // operands of this wave's first later block (rows of block j, its 64 columns): in flight under the decisions
+        const int jb_first = j + 1 + wave;
+        float qpre[16][4];
+        if (jb_first < nbg) {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int row = R0 + 4 * ks + lq;
+                    qpre[ks][ct] = row < a.n ? a.Q2[(size_t)row * a.stride + (size_t)(kXgGrp * g + jb_first) * kXgB + 16 * ct + lr] : 0.0f;
+                }
+        }
+        for (int e = tid; e < kXgB * kXgB / 4; e += 256) {
+            const int k = e >> 4, c = e & 15;                             // columns R0 + 4 c .. + 3: q = 0..3 at m = c
+            f32x4acc v = {0, 0, 0, 0};
+            if (R0 + k < a.n) v = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)(R0 + k) * a.stride + R0 + 4 * c);
+            Ct[k][0][c] = v[0]; Ct[k][1][c] = v[1]; Ct[k][2][c] = v[2]; Ct[k][3][c] = v[3];
+        }
+        const unsigned long long xw = a.XT[(size_t)b * a.Rp + r];
+        float t[16], th[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) th[m] = a.TH[((size_t)j * 64 + q + 4 * m) * a.Rp + r];
+        if (j == 0) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) t[m] = a.F[fidx(a, R0 + q + 4 * m, r)];
+        }
+        __syncthreads();                                       // Ct staged; Fo carries the rows of blocks < j
+        if (j > 0) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) t[m] = Fo[j - 1][q + 4 * m][rl];
+        }
+        unsigned long long word = 0;
+        bool any = false;
+        static_for<0, kXgB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int mk = k >> 2, qk = k & 3;
+            // the coupling row of step k is read before its decision is known (at the hot end every row is flipped by
+            // some replica of the wavefront): its LDS latency runs beside the decision instead of behind it
+            f32x4acc c4[4];
+#pragma unroll
+            for (int g4 = mk >> 2; g4 < 4; ++g4) c4[g4] = *reinterpret_cast<const f32x4acc *>(&Ct[k][q][4 * g4]);
+            const bool xk = ((xw >> k) & 1ull) != 0ull;
+            const float dE = xk ? -t[mk] : t[mk];
+            const bool acc = (q == qk) && dE < th[mk];                    // the lane that holds row k
+            const float so = acc ? (xk ? -1.0f : 1.0f) : 0.0f;
+            const float sk = xg_quad_bcast<qk>(so);
+            if (q == qk) Sl[k][rl] = so;
+            if (acc) { word |= 1ull << k; ++accepted; }
+            if (__ballot(acc) != 0ull) {                                  // (wave-uniform: nobody flipped row k)
+#pragma unroll
+                for (int g4 = mk >> 2; g4 < 4; ++g4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[4 * g4 + i] = __fmaf_rn(c4[g4][i], sk, t[4 * g4 + i]);
+                }
+                any = any || acc;
+            }
+        });
+        {   // the quad's accepted rows -> the replica's state word
+            unsigned int lo = (unsigned int)word, hi = (unsigned int)(word >> 32);
+            lo |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, false);
+            hi |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, false);
+            lo |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, false);
+            hi |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xf, 0xf, false);
+            if (q == 0) a.XT[(size_t)b * a.Rp + r] = xw ^ (((unsigned long long)hi << 32) | lo);
+        }
+        if (__ballot(any) != 0ull && lane == 0) atomicOr(&any_s[j], 1);
+        __syncthreads();                                       // signs in Sl, the block's flag complete
+        for (int e = tid; e < kXgB * kXgReps / 4; e += 256) {  // ... and on their way to HBM for the group's full pass
+            const int k = e >> 4, r4 = (e & 15) * 4;
+            *reinterpret_cast<f32x4acc *>(Sj + (size_t)k * a.Rp + blockIdx.x * 64 + r4) = *reinterpret_cast<const f32x4acc *>(&Sl[k][r4]);
+        }
+        const bool live = any_s[j] != 0;
+        if (tid == 0) a.flags[((size_t)par * kXgGrp + j) * ranges + blockIdx.x] = live ? 1u : 0u;
+        if (live) {
+            // rows of block j onto the columns of the later blocks: C[i = replica][j = column] tiles, chained in row order
+            for (int jb = jb_first; jb < nbg; jb += 4) {
+                if (jb != jb_first) {
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) {
+                            const int row = R0 + 4 * ks + lq;
+                            qpre[ks][ct] = row < a.n ? a.Q2[(size_t)row * a.stride + (size_t)(kXgGrp * g + jb) * kXgB + 16 * ct + lr] : 0.0f;
+                        }
+                }
+                f32x4acc acc[4][4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = *reinterpret_cast<const f32x4acc *>(&Fo[jb - 1][16 * ct + lr][16 * rt + 4 * lq]);
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    float sa[4];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) sa[rt] = Sl[4 * ks + lq][16 * rt + lr];                    // A[i = lr][k = lq]
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[rt], qpre[ks][ct], acc[rt][ct], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4acc *>(&Fo[jb - 1][16 * ct + lr][16 * rt + 4 * lq]) = acc[rt][ct];
+            }
+        }
+        __syncthreads();                                       // Fo, Ct and Sl are free for the next block
+    }
+    // accepted flips of this wavefront -> stats[1]
+    unsigned long long tot = accepted;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    if (lane == 0 && tot) atomicAdd(&a.stats[1], tot);
+}
+
 // ---- PANEL: fields (+)= sum over rows of Q2[row][col] * S[row][r], the rows in order, as chained MFMAs ----
 // workgroup = 256 columns x 64 replicas, wave w = 64 columns: 4 x 4 tiles, C[i = replica][j = column].
 //   MINI = false: the whole group g (blocks G g .. G g + nbg - 1, G = kXgGrp; 64 nbg rows) onto ALL columns of F -- F is read and
@@ -376,7 +527,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     a.temps = x.temps; a.init = x.init; a.states = x.states; a.energy = x.energy; a.stats = x.stats; a.offset = x.offset;
     a.replica_offset = x.replica_offset; a.seed_lo = x.seed_lo; a.seed_hi = x.seed_hi;
     a.temps_per_replica = x.temps_per_replica;
-    note_kernel("k_xg_diag + k_xg_panel (K1g, %d blocks of 64 rows in groups of %d)", a.nblocks, kXgGrp);
+
 
     if (begin) {
         HIP_TRY(hipMemsetAsync(a.XT, 0, (size_t)a.nblocks * a.Rp * 8, st));     // (replicas past R: no bits)
@@ -387,6 +538,12 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
     // Each stream gets its own compute units: the chain's kernels are small (4 .. 16 workgroups) and latency-critical,
     // and behind a full pass that keeps every CU filled from its 3000-workgroup grid they were not scheduled until
     // the pass had drained (measured: a 23 us DIAG took 234 us) -- 8 of the 256 CUs are set aside for them.
+    // one chain launch per group (k_xg_chain, a whole CU per 64 replicas) / a DIAG and a small pass per block: the fused
+    // kernel wins where the chain bounds the run (few replica ranges; 145 against 154 ms at n = 50 000, 64 replicas x 4
+    // sweeps) and is neutral at 1024 replicas, where it would need 16 of the CUs
+    const bool fused = x.xg_chain == 2 || (x.xg_chain == 0 && (x.R + 255) / 256 * 256 / kXgReps <= 8);
+    note_kernel(fused ? "k_xg_chain + k_xg_panel (K1g, %d blocks of 64 rows in groups of %d)"
+                      : "k_xg_diag + k_xg_panel (K1g, %d blocks of 64 rows in groups of %d)", a.nblocks, kXgGrp);
     XgSync sync;
     hipStream_t sa = st, sb = st;                             // (fallback without CU masks: one stream, same order)
     bool own_streams = false;
@@ -396,7 +553,10 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         const int words = (ncu + 31) / 32;
         std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
-        for (int c = 0; c < ncu; ++c) (c < 8 ? mb : ma)[(size_t)c / 32] |= 1u << (c % 32);
+        // (the fused chain kernel takes a whole CU per 64 replicas: 156 KB of LDS)
+        const int ranges = a.Rp / kXgReps;
+        const int chain_cus = fused ? (ranges < 8 ? 8 : (ranges > 32 ? 32 : ranges)) : 8;
+        for (int c = 0; c < ncu; ++c) (c < chain_cus ? mb : ma)[(size_t)c / 32] |= 1u << (c % 32);
         hipStream_t ta = nullptr, tb = nullptr;
         const char *one = getenv("MI_XG_ONE_STREAM");       // (tests: the fallback order on the caller's stream)
         if (!(one && one[0] == '1') && ncu >= 64 && hipExtStreamCreateWithCUMask(&ta, (uint32_t)words, ma.data()) == hipSuccess) {
@@ -461,10 +621,14 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
             if (!ps.force)
                 for (int h = 0; 4 * h < nbg; ++h)
                     hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, sb, a, g * (kXgGrp / 4) + h, ps.sweep, ps.s_local, 4 * h);
-            for (int j = 0; j < nbg; ++j) {
-                hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, sb, a, kXgGrp * g + j, ps.force, par);
-                if (!ps.force && j + 1 < nbg)
-                    hipLaunchKernelGGL(k_xg_panel<true>, dim3(a.Rp / kXgReps, (nbg - 1 - j + 3) / 4), dim3(256), 0, sb, a, g, nbg, j, par, -1, -1);
+            if (fused && !ps.force) {
+                hipLaunchKernelGGL(k_xg_chain, gdiag, dim3(256), 0, sb, a, g, nbg, par);
+            } else {
+                for (int j = 0; j < nbg; ++j) {
+                    hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, sb, a, kXgGrp * g + j, ps.force, par);
+                    if (!ps.force && j + 1 < nbg)
+                        hipLaunchKernelGGL(k_xg_panel<true>, dim3(a.Rp / kXgReps, (nbg - 1 - j + 3) / 4), dim3(256), 0, sb, a, g, nbg, j, par, -1, -1);
+                }
             }
             HIP_TRY(hipEventRecord(evS[G & 3], sb));
             // ---- the group's full pass over F: the next group's own 256 columns on B (in front of that group's chain; they

@@ -167,6 +167,7 @@ struct mi_sa_problem {
     void *d_xg = nullptr;                    // K1g workspace (fields of all replicas, state words, signs, thresholds)
     size_t xg_bytes = 0;
     int opt_xl_batched = 0;                  // n > 4096: 0 auto (K1g for >= 256 replicas or n >= 16384), 1 always K1g, 2 always K1x
+    int opt_xl_chain = 0;                    // K1g, chain of a group of blocks: 0 auto (fused up to 512 replicas), 1 a DIAG and a small pass per block, 2 fused
     int opt_xl_chunk = 8;                    // K1g: sweeps per chunk of a cooling run (the hand-over to K1x is decided per chunk)
     int opt_xl_cold_permille = 20;           // hand the rest of the run to K1x when a chunk accepted less than this share (0 = never)
     int xl_chunks = 0;
@@ -794,6 +795,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "pace")) { p->opt_pace = value != 0; return MI_OK; }
     if (!strcmp(key, "xl_batched") && value >= 0 && value <= 2) { p->opt_xl_batched = (int)value; return MI_OK; }
     if (!strcmp(key, "xl_chunk") && value >= 1) { p->opt_xl_chunk = (int)value; return MI_OK; }
+    if (!strcmp(key, "xl_chain") && value >= 0 && value <= 2) { p->opt_xl_chain = (int)value; return MI_OK; }
     if (!strcmp(key, "xl_cold_permille") && value >= 0 && value <= 1000) { p->opt_xl_cold_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "mfma_permille") && value >= 0 && value <= 1000) { p->opt_mfma_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "chunk_sweeps") && value >= 0) { p->opt_chunk_sweeps = (int)value; return MI_OK; }
@@ -856,6 +858,7 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         a.offset = p->offset; a.n = p->n; a.R = R; a.num_sweeps = num_sweeps; a.resync = resync_interval;
         a.replica_offset = replica_offset; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
+        a.xg_chain = p->opt_xl_chain;
         p->last_launches = 1;
         // K1x pays per accepted flip (a barrier and the L2 latency of one Q row: ~1 us up to n = 8192, 3 us at 20 000,
         // 8 us at 50 000) and runs 256 replicas at a time; K1g pays ~25 us per 64 rows whatever the replica count

@@ -283,6 +283,7 @@ struct DenseXlArgs {
     // (fin_ncols columns per replica range); nullptr = build the fields from the states (as at the start of a run)
     const float *fields_in = nullptr;
     int fin_ncols = 0;
+    int xg_chain = 0;       // K1g, the chain of a group of blocks: 0 auto, 1 = a DIAG and a small pass per block, 2 = one launch (k_xg_chain)
 };
 int mi_launch_dense_xl(const DenseXlArgs &, int chunks, hipStream_t);
 // K1g (dense_xg_kernels.hip): the same run for many replicas at once, row updates as a GEMM-shaped pass per 64 rows

@@ -361,8 +361,11 @@ def test_dense_beyond_4096_variables_workgroup_per_replica(n, R, sweeps):
         with Problem.dense(Qs) as p:
             # 2 = K1x (a workgroup per replica); 1 = K1g (all replicas together, 64 rows per GEMM-shaped pass on the matrix
             # cores -- what runs of >= 256 replicas, or of n >= 16384, take by default)
-            for mode, name in ((2, "k_anneal_dense_xl"), (1, "k_xg_diag + k_xg_panel")):
+            # K1g's chain of a group of eight blocks: one fused launch (2; the default up to 512 replicas), or a DIAG + a
+            # small pass per block (1)
+            for mode, chain, name in ((2, 0, "k_anneal_dense_xl"), (1, 2, "k_xg_chain + k_xg_panel"), (1, 1, "k_xg_diag + k_xg_panel")):
                 p.set_option("xl_batched", mode)
+                p.set_option("xl_chain", chain)
                 p.anneal(R, betas, 11, replica_offset=5, initial_states=kw.get("init"),
                          resync_interval=kw.get("resync_interval", 0))
                 st, en, info = p.fetch()
@@ -385,7 +388,7 @@ def test_batched_dense_kernel_many_replicas_equal_workgroup_per_replica():
     betas = np.geomspace(0.05, 20.0, 6)
     with Problem.dense(Qs) as p:
         p.anneal(R, betas, 3, resync_interval=4)
-        assert p.kernel_name().startswith("k_xg_diag")                      # the default for >= 256 replicas
+        assert p.kernel_name().startswith("k_xg_chain")                     # the default for >= 256 replicas (fused chain up to 512)
         st, en, info = p.fetch()
         p.set_option("xl_batched", 2)
         p.anneal(R, betas, 3, resync_interval=4)
@@ -409,7 +412,7 @@ def test_batched_dense_kernel_many_replicas_equal_workgroup_per_replica():
         p.anneal(R, cool, 9)
         name = p.kernel_name()
         got = p.fetch()
-        assert "k_xg_diag" in name and "k_anneal_dense_xl" in name
+        assert "k_xg_chain" in name and "k_anneal_dense_xl" in name
         assert np.array_equal(got[0], ref[0]) and got[2]["accepted"] == ref[2]["accepted"]
         assert np.allclose(got[1], ref[1], rtol=1e-6)
         p.set_option("xl_cold_permille", 0)                   # never hand over: K1g alone, same result
@@ -417,6 +420,13 @@ def test_batched_dense_kernel_many_replicas_equal_workgroup_per_replica():
         assert "dense_xl" not in p.kernel_name()
         alone = p.fetch()
         assert np.array_equal(alone[0], ref[0]) and alone[2]["accepted"] == ref[2]["accepted"]
+        p.set_option("xl_chain", 1)                           # a DIAG and a small pass per block instead of the fused chain
+        p.anneal(R, cool, 9)
+        assert p.kernel_name().startswith("k_xg_diag")
+        per_block = p.fetch()
+        p.set_option("xl_chain", 0)
+        assert np.array_equal(per_block[0], ref[0]) and per_block[2]["accepted"] == ref[2]["accepted"]
+        assert np.array_equal(per_block[1], alone[1])         # the same cached fields, bit for bit
         import os
         os.environ["MI_XG_ONE_STREAM"] = "1"                  # without CU-masked streams: the same kernels in one stream
         try:
@@ -464,13 +474,13 @@ def test_full_size_properties_config4_dense_50k():
         p.set_option("xl_batched", 1)                         # K1g: the same two replicas through the batched passes
         p.anneal(2, betas, 77, replica_offset=4094)
         stg, eng, infog = p.fetch()
-        assert p.kernel_name().startswith("k_xg_diag")
+        assert p.kernel_name().startswith("k_xg_chain")
         assert np.array_equal(stg, st) and infog["accepted"] == info["accepted"] and np.allclose(eng, en, rtol=1e-6)
         # and a full first wave of workgroups: 256 replicas x 1 sweep at the hot end, K1g (its default) against K1x
         hot = models.make_beta_schedule(1000, models.default_beta_range(m))[:1]
         p.set_option("xl_batched", 0)
         p.anneal(256, hot, 5)
-        assert p.kernel_name().startswith("k_xg_diag")
+        assert p.kernel_name().startswith("k_xg_chain")
         sg, eg, ig = p.fetch()
         p.set_option("xl_batched", 2)
         p.anneal(256, hot, 5)
