@@ -28,7 +28,7 @@ from typing import Optional
 
 import numpy as np
 
-from .models import (add_size_window_penalty, build_bqm2_qubo, build_bqm3_cut_qubo, build_bqm_qubo,
+from .models import (RootGraphArrays, add_size_window_penalty, build_bqm2_qubo, build_bqm3_cut_qubo, build_bqm_qubo,
                      build_dqm_potts)
 
 
@@ -80,9 +80,12 @@ def _solve(G, model, dirs, solver, sampler, num_reads, chain_strength, sampler_k
 
 
 def clustering_bqm(G, iteration, dirs, solver, gamma_factor, color, terminate_on, size_limit, iter_limit,
-                   chain_strength, sampler=None, sampler_kwargs: Optional[dict] = None, verbose=False):
-    """Recursive 2-way partition with the balanced-cut QUBO (BQM_clustering.py:25-204)."""
-    model = build_bqm_qubo(G, gamma_factor, k=8)                      # :29-47
+                   chain_strength, sampler=None, sampler_kwargs: Optional[dict] = None, verbose=False, _arrays=None):
+    """Recursive 2-way partition with the balanced-cut QUBO (BQM_clustering.py:25-204).  ``_arrays``: the root graph's
+    adjacency as arrays, built by the outermost call and handed down the recursion (models.RootGraphArrays)."""
+    if _arrays is None:
+        _arrays = RootGraphArrays.of(G)
+    model = build_bqm_qubo(G, gamma_factor, k=8, arrays=_arrays)     # :29-47
     if verbose:
         print("gamma: ", model.info["gamma"])
         print("... Running on MI355X ...")
@@ -98,7 +101,7 @@ def clustering_bqm(G, iteration, dirs, solver, gamma_factor, color, terminate_on
         for part in (S0, S1):
             clustering_bqm(G.subgraph(part), iteration + 1, dirs, solver, gamma_factor, color + 20,
                            terminate_on, size_limit, iter_limit, chain_strength, sampler=sampler,
-                           sampler_kwargs=sampler_kwargs, verbose=verbose)
+                           sampler_kwargs=sampler_kwargs, verbose=verbose, _arrays=_arrays)
 
     if terminate_on == "min_size":                                    # :113-130
         if len(S0) > size_limit and len(S1) > size_limit and iteration < iter_limit:
@@ -144,10 +147,12 @@ def clustering_bqm(G, iteration, dirs, solver, gamma_factor, color, terminate_on
 
 
 def clustering_bqm_2(G, iteration, dirs, solver, gamma_factor, color, terminate_on, size_limit, k,
-                     chain_strength, sampler=None, sampler_kwargs: Optional[dict] = None, verbose=False):
+                     chain_strength, sampler=None, sampler_kwargs: Optional[dict] = None, verbose=False, _arrays=None):
     """Recursive 2-way partition with the linear-penalty QUBO (BQM_clustering.py:206-351).  As in the
     reference the ``chain_strength`` argument is replaced by mean(w) * mean(deg) * 2 (:220)."""
-    model = build_bqm2_qubo(G, gamma_factor, k)                       # :210-236
+    if _arrays is None:
+        _arrays = RootGraphArrays.of(G)
+    model = build_bqm2_qubo(G, gamma_factor, k, arrays=_arrays)      # :210-236
     chain_strength = model.info["chain_strength"]
     if verbose:
         print("gamma: ", model.info["gamma"])
@@ -164,7 +169,7 @@ def clustering_bqm_2(G, iteration, dirs, solver, gamma_factor, color, terminate_
         for part in (S0, S1):                                         # :317-318, :338-339
             clustering_bqm_2(G.subgraph(part), iteration + 1, dirs, solver, gamma_factor, color + 20,
                              terminate_on, size_limit, k, chain_strength, sampler=sampler,
-                             sampler_kwargs=sampler_kwargs, verbose=verbose)
+                             sampler_kwargs=sampler_kwargs, verbose=verbose, _arrays=_arrays)
 
     if terminate_on == "min_size":                                    # :302-318
         for i in S0:                                                  # deterministic colours here (:306, :311)

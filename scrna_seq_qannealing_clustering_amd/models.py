@@ -26,14 +26,100 @@ def _is_simple_networkx_graph(G) -> bool:
             and not G.is_directed() and not G.is_multigraph())
 
 
-def graph_arrays_and_weight(G):
+class RootGraphArrays:
+    """The adjacency of a simple networkx graph as arrays, in adjacency order -- built by ONE walk, then reused for every
+    ``G.subgraph(part)`` view a recursive bisection takes of it (BQM_clustering.py:121-122; networkx collapses a
+    subgraph of a subgraph view into a view of the root graph with a new node set).  ``arrays_for(view)`` returns what
+    ``graph_arrays_and_weight(view)`` returns, entry for entry and bit for bit, without walking the view in Python:
+
+    * nodes: ``list(view.nodes)`` -- networkx's own iteration (it depends on the size of the node set);
+    * a neighbour dict of a view iterates the ROOT's dict in its order, filtered by the node set, unless the set has
+      less than half as many nodes as the dict has entries -- then (tiny subgraphs only) this class steps aside;
+    * an edge is reported at the endpoint that comes first in node order (the ``seen`` set of ``G.edges``);
+    * ``W = G.size(weight)``: per-node weighted degree added up in adjacency order (``np.bincount`` adds its weights
+      one after the other, as the Python loop does; a self-loop twice), then Python's ``sum`` over the nodes, halved.
+
+    The edge weights of the root must not change while the object is in use (a clustering run does not change them)."""
+
+    def __init__(self, root):
+        self.graph = root
+        nodes = list(root._adj)
+        self.index = {v: i for i, v in enumerate(nodes)}
+        index = self.index
+        counts = np.fromiter((len(nbrs) for nbrs in root._adj.values()), dtype=np.int64, count=len(nodes))
+        self.rowptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        col: List[int] = []
+        w: List[float] = []
+        self.ok = True
+        for nbrs in root._adj.values():
+            for v, data in nbrs.items():
+                col.append(index[v])
+                wt = data.get("weight")
+                if wt is None or isinstance(wt, bool) or not isinstance(wt, (int, float)):
+                    self.ok = False                      # (unweighted / exotic weights: the plain walk decides what happens)
+                    wt = 0.0
+                w.append(wt)
+        self.col = np.asarray(col, dtype=np.int64)
+        self.w = np.asarray(w, dtype=np.float64)
+        self.max_degree = int(counts.max()) if len(counts) else 0
+
+    @staticmethod
+    def of(G):
+        """For a simple networkx graph or a node-induced view of one; None for anything else."""
+        if not _is_simple_networkx_graph(G):
+            return None
+        root = G._graph if hasattr(G, "_NODE_OK") else G
+        if hasattr(root, "_NODE_OK") or not hasattr(root, "_adj") or not _is_simple_networkx_graph(root):
+            return None
+        arrays = RootGraphArrays(root)
+        return arrays if arrays.ok else None
+
+    def arrays_for(self, G):
+        if G is self.graph:
+            nodes = list(G.nodes)
+        else:
+            try:
+                import networkx as nx
+                ok = (G._graph is self.graph and G._EDGE_OK is nx.filters.no_filter and hasattr(G._NODE_OK, "nodes"))
+            except Exception:
+                ok = False
+            if not ok or 2 * len(G._NODE_OK.nodes) < self.max_degree:
+                return None
+            nodes = list(G.nodes)
+        n = len(nodes)
+        if n == 0:
+            return None
+        root_idx = np.fromiter((self.index[v] for v in nodes), dtype=np.int64, count=n)
+        pos = np.full(len(self.index), -1, dtype=np.int64)
+        pos[root_idx] = np.arange(n)
+        start, cnt = self.rowptr[root_idx], self.rowptr[root_idx + 1] - self.rowptr[root_idx]
+        total = int(cnt.sum())
+        row = np.repeat(np.arange(n), cnt)
+        flat = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt) + np.repeat(start, cnt)
+        nb = pos[self.col[flat]]
+        keep = nb >= 0
+        row, nb, ww = row[keep], nb[keep], self.w[flat][keep]
+        twice = np.where(nb == row, 2, 1)                                   # a self-loop enters its degree twice, back to back
+        deg = np.bincount(np.repeat(row, twice), weights=np.repeat(ww, twice), minlength=n)
+        W = float(sum(deg.tolist()) / 2)
+        first = nb >= row                                                   # the other endpoint has not been visited yet
+        return (nodes, row[first].astype(np.int32), nb[first].astype(np.int32), ww[first], W)
+
+
+def graph_arrays_and_weight(G, arrays: Optional["RootGraphArrays"] = None):
     """``(nodes, eu, ev, w, W)``: the arrays of ``graph_arrays`` and ``W = G.size(weight="weight")`` from ONE walk over the
     adjacency.  On a networkx graph the three calls the reference makes (``number_of_edges``, ``edges``, ``size``) are
     three walks, and on the subgraph VIEWS the recursive bisection hands down (``G.subgraph(part)``,
     BQM_clustering.py:121-122) every step of a walk goes through the view's node filter: 2/3 of the model-build time
     of a 4-level bisection.  Same edge order as ``G.edges`` (an edge is reported at its first endpoint in node order,
     neighbours in adjacency order) and the same summation as ``Graph.size`` (per-node weighted degree in adjacency
-    order, self-loops twice, summed over the nodes with ``sum``, halved), so gamma stays bit-identical."""
+    order, self-loops twice, summed over the nodes with ``sum``, halved), so gamma stays bit-identical.
+    ``arrays``: the root graph's ``RootGraphArrays`` -- the same result from array operations (a clustering run builds
+    it once and hands it down its recursion)."""
+    if arrays is not None:
+        got = arrays.arrays_for(G)
+        if got is not None:
+            return got
     if not _is_simple_networkx_graph(G):
         nodes, eu, ev, w = _graph_arrays_by_calls(G)
         return nodes, eu, ev, w, _graph_total_weight(G, w)
@@ -102,13 +188,15 @@ def _csr_from_edges(n: int, eu: np.ndarray, ev: np.ndarray, val: np.ndarray):
     key = rows * n + cols
     order = np.argsort(key, kind="stable")
     key, vals = key[order], vals[order]
-    uniq, start = np.unique(key, return_index=True)
-    summed = np.add.reduceat(vals, start) if len(vals) else vals
+    if len(key):
+        start = np.flatnonzero(np.concatenate([[True], key[1:] != key[:-1]]))       # first entry of every (row, col) run
+        uniq = key[start]
+        summed = np.add.reduceat(vals, start)
+    else:
+        uniq, summed = key, vals
     r = (uniq // n).astype(np.int32)
     c = (uniq % n).astype(np.int32)
-    rowptr = np.zeros(n + 1, dtype=np.int32)
-    np.add.at(rowptr, r + 1, 1)
-    rowptr = np.cumsum(rowptr).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))]).astype(np.int32)
     return rowptr, c, summed
 
 
@@ -178,12 +266,12 @@ def _cut_qubo_parts(n, eu, ev, w, k):
     return lin, k * -2 * w
 
 
-def build_bqm_qubo(G, gamma_factor: float, k: float = 8) -> QuboModel:
+def build_bqm_qubo(G, gamma_factor: float, k: float = 8, arrays=None) -> QuboModel:
     """A1 -- `clustering_bqm` model, BQM_clustering.py:29-47:
     ``gamma = gamma_factor * W / n``; cut term with ``k = 8`` (:33); ``Q[i,i] += gamma (1 - n)``
     (:43-44); ``Q[i,j] += 2 gamma`` for every pair (:46-47).  Closed form
-    ``E = k cut_w + gamma (s^2 - n s)``."""
-    nodes, eu, ev, w, W = graph_arrays_and_weight(G)
+    ``E = k cut_w + gamma (s^2 - n s)``.  ``arrays``: see ``graph_arrays_and_weight``."""
+    nodes, eu, ev, w, W = graph_arrays_and_weight(G, arrays)
     n = len(nodes)
     gamma = gamma_factor * W / n
     lin, pair = _cut_qubo_parts(n, eu, ev, w, k)
@@ -193,11 +281,11 @@ def build_bqm_qubo(G, gamma_factor: float, k: float = 8) -> QuboModel:
                      info={"gamma": gamma, "k": k, "W": W, "kind": "bqm"})
 
 
-def build_bqm2_qubo(G, gamma_factor: float, k: float) -> QuboModel:
+def build_bqm2_qubo(G, gamma_factor: float, k: float, arrays=None) -> QuboModel:
     """A2 -- `clustering_bqm_2` model, BQM_clustering.py:210-236: ``gamma = (W / n) gamma_factor``
     (:222), cut term with caller's k (:230-233), linear-only penalty ``Q[i,i] += gamma`` (:235-236);
     also the QPU-only ``chain_strength = mean(w) mean(deg) 2`` (:212-220) for reporting."""
-    nodes, eu, ev, w, W = graph_arrays_and_weight(G)
+    nodes, eu, ev, w, W = graph_arrays_and_weight(G, arrays)
     n = len(nodes)
     gamma = (W / n) * gamma_factor
     lin, pair = _cut_qubo_parts(n, eu, ev, w, k)

@@ -249,3 +249,49 @@ def test_one_walk_graph_arrays_equal_the_networkx_calls_on_subgraph_views():
     view, copy = G.subgraph(part), nx.Graph(G.subgraph(part))
     mv, mc = models.build_bqm_qubo(view, 0.05), models.build_bqm_qubo(copy, 0.05)
     assert mv.info["gamma"] == mc.info["gamma"] and np.array_equal(mv.lin, mc.lin) and np.array_equal(mv.val, mc.val)
+
+
+def test_root_graph_arrays_give_every_subgraph_view_without_a_python_walk():
+    """`RootGraphArrays` (one walk over the root graph, then array operations per `G.subgraph(part)` view -- what a
+    recursive bisection hands down): node list, edge order, weights and total weight bit-identical to the plain walk
+    and to networkx's own calls, on the root, on views of either iteration order, on views of views (networkx
+    collapses them onto the root), with self-loops and integer weights; views smaller than half a neighbour list,
+    copies and foreign graphs are declined (None) and take the plain walk."""
+    import networkx as nx
+    from scrna_seq_qannealing_clustering_amd.graphs import graph_from_edges, synthetic_snn
+    nodes, eu, ev, w, _ = synthetic_snn(700, 5, 15, 15, 4, seed=3)
+    G = graph_from_edges(nodes, eu, ev, w)
+    G.add_edge(nodes[5], nodes[5], weight=0.37)
+    G.add_edge(nodes[9], nodes[9], weight=3)
+    G.add_edge(nodes[9], nodes[11], weight=2)
+    arrays = models.RootGraphArrays.of(G)
+    assert arrays is not None and arrays.graph is G
+    part = [v for i, v in enumerate(G.nodes) if (i * 7) % 3 != 0]
+    rs = np.random.RandomState(4)
+    shuffled = [part[i] for i in rs.permutation(len(part))]
+    views = [G, G.subgraph(part), G.subgraph(shuffled), G.subgraph(part).subgraph(part[::2]), G.subgraph(part[::5]),
+             G.subgraph(part).subgraph(part[::2]).subgraph(part[::4]), G.subgraph([nodes[5], nodes[9], nodes[11]] + part[:40])]
+    for H in views:
+        assert models.RootGraphArrays.of(H).graph is G            # found from any of its views
+        got = arrays.arrays_for(H)
+        want = models.graph_arrays_and_weight(H)
+        assert got is not None and got[0] == want[0] == list(H.nodes)
+        assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(got[1:4], want[1:4]))
+        assert got[4] == want[4] == float(H.size(weight="weight"))
+        assert [(got[0][a], got[0][b]) for a, b in zip(got[1], got[2])] == [(u, v) for u, v in H.edges]
+        ma, mp = models.build_bqm_qubo(H, 0.05, arrays=arrays), models.build_bqm_qubo(H, 0.05)
+        assert ma.info["gamma"] == mp.info["gamma"] and np.array_equal(ma.lin, mp.lin)
+        assert np.array_equal(ma.rowptr, mp.rowptr) and np.array_equal(ma.col, mp.col) and np.array_equal(ma.val, mp.val)
+    hub = nx.Graph()                                              # a neighbour list more than twice the size of the view:
+    hub.add_weighted_edges_from((0, i, 1.0 + i) for i in range(1, 40))   # networkx walks the node SET there -- declined
+    hub.add_weighted_edges_from((i, i + 1, 0.5) for i in range(1, 39))
+    ha = models.RootGraphArrays.of(hub)
+    tiny = hub.subgraph([0, 3, 4, 17, 18])
+    assert ha.arrays_for(tiny) is None
+    got, want = models.graph_arrays_and_weight(tiny, ha), models.graph_arrays_and_weight(tiny)
+    assert got[0] == want[0] and all(np.array_equal(a, b) for a, b in zip(got[1:4], want[1:4])) and got[4] == want[4]
+    assert arrays.arrays_for(nx.Graph(G.subgraph(part))) is None      # a copy is a graph of its own
+    assert arrays.arrays_for(hub.subgraph(range(30))) is None         # a view of another graph
+    unweighted = nx.path_graph(5)
+    assert models.RootGraphArrays.of(unweighted) is None              # no weights: the plain walk decides (it raises)
+    assert models.RootGraphArrays.of(nx.DiGraph()) is None
