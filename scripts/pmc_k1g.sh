@@ -14,13 +14,15 @@ for ctrs in "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_W
 done
 python3 - <<PY
 import csv, collections
-tot = collections.defaultdict(float); n = collections.defaultdict(int)
+tot = collections.defaultdict(float); n = collections.defaultdict(int); dur = []
 for i in (1, 2):
     for r in csv.DictReader(open("$out/p%d.csv" % i)):
         if int(r["Grid_Size"]) < 100000: continue      # the 16-workgroup first parts
         tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE": dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k in sorted(tot): print("%-28s %.4g per launch (%d launches)" % (k, tot[k] / n[k], n[k]))
 cyc = tot["GRBM_GUI_ACTIVE"] / n["GRBM_GUI_ACTIVE"] / 8
+print("launch duration %.1f us under the counters: clock %.3f GHz" % (sum(dur) / len(dur) / 1e3, cyc / (sum(dur) / len(dur))))
 print("cycles per launch", cyc, "MFMA busy frac", tot["SQ_VALU_MFMA_BUSY_CYCLES"] / n["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc))
 w = tot["SQ_WAVE_CYCLES"]
 print("waves: active %.3f stalled-at-issue %.3f parked %.3f wait-LDS %.3f" % (tot["SQ_ACTIVE_INST_ANY"] / w, tot["SQ_WAIT_INST_ANY"] / w, tot["SQ_WAIT_ANY"] / w, tot["SQ_WAIT_INST_LDS"] / w))

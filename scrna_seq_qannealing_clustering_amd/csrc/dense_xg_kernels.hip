@@ -389,14 +389,20 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     if (live == 0u && !(MINI && j == 0)) return;              // (the first MINI of a group also COPIES F into Tm)
     const bool wave_on = !MINI || 4 * yy + wave < nbg - 1 - j;   // MINI: one wave per later block of the group
 
+    // chunk and sign loads through buffer descriptors with a UNIFORM base per chunk / block (scalar arithmetic) and
+    // per-thread offsets that never change -- no 64-bit address arithmetic in vector registers (the kernel lives on 128
+    // of them); rows past n are outside the descriptor and read as zero
     f32x4acc pre[CR / 4];
+    const int vq = (int)(((size_t)(tid >> 6) * a.stride + 4 * (tid & 63)) * 4);
+    const int sq = (int)(4 * a.stride * 4);                  // four rows on: the soffset step of a thread's next piece
     auto fetch_chunk = [&](int jj, int c) {                   // rows 16 c .. 16 c + 15 of block kXgGrp g + jj, columns col0 ..
+        const int row0 = (kXgGrp * g + jj) * kXgB + CR * c;
+        const int valid = a.n - row0 < 0 ? 0 : (a.n - row0 > CR ? CR : a.n - row0);
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.Q2 + (size_t)row0 * a.stride + col0), 0, (int)((size_t)valid * a.stride * 4), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < CR / 4; ++i) {
-            const int row = (kXgGrp * g + jj) * kXgB + CR * c + 4 * i + (tid >> 6), col = col0 + 4 * (tid & 63);
-            pre[i] = f32x4acc{0, 0, 0, 0};
-            if (row < a.n && (size_t)col < a.stride) pre[i] = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)row * a.stride + col);
-        }
+        for (int i = 0; i < CR / 4; ++i)
+            pre[i] = __builtin_bit_cast(f32x4acc, __builtin_amdgcn_raw_buffer_load_b128(rq, vq, i * sq, 0));
     };
     // accumulators: tile (rt, ct): replicas rep0 + 16 rt + 4 lq + reg, column 64 wave + 16 ct + lr of the workgroup's 256
     auto field_ptr = [&](bool dst, int ct, int rt) -> float * {
@@ -414,38 +420,60 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = *reinterpret_cast<const f32x4acc *>(field_ptr(false, ct, rt));
     }
-#pragma unroll 1
-    for (int jj = jb0; jj < jb1; ++jj) {
-        if (!((live >> jj) & 1u)) continue;                   // uniform: no flip of this block in these replicas
+    // The chunks of all live blocks are ONE stream: chunk t + 1 (the next block's first chunk included) and the next
+    // block's signs travel from HBM to registers under the MFMAs of chunk t, so that a block boundary costs a barrier
+    // and two LDS writes, not a round trip to memory (it did: eight exposed fetches per workgroup, and the four
+    // workgroups of a CU pay them in lock-step).
+    f32x4acc spre[kXgB * kXgReps / 4 / 256];
+    const int vs = ((tid >> 4) * a.Rp + (tid & 15) * 4) * 4;
+    auto fetch_signs = [&](int jj) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            a.S + ((size_t)par * kXgGrp + jj) * kXgB * a.Rp + rep0, 0, kXgB * a.Rp * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < kXgB * kXgReps / 4 / 256; ++i)   // rows (tid >> 4) + 16 i
+            spre[i] = __builtin_bit_cast(f32x4acc, __builtin_amdgcn_raw_buffer_load_b128(rs, vs, i * 16 * a.Rp * 4, 0));
+    };
+    unsigned int todo = live & ~((1u << jb0) - 1u) & ((jb1 >= 32) ? ~0u : ((1u << jb1) - 1u));
+    if (todo != 0u) {
+        int jj = __builtin_ctz(todo);
         fetch_chunk(jj, 0);
-        __syncthreads();                                       // (Ssl of the previous block consumed)
-        for (int e = tid; e < kXgB * kXgReps / 4; e += 256) {
-            const int k = e >> 4, j4 = (e & 15) * 4;
-            *reinterpret_cast<f32x4acc *>(&Ssl[k][j4]) =
-                *reinterpret_cast<const f32x4acc *>(a.S + (((size_t)par * kXgGrp + jj) * kXgB + k) * a.Rp + rep0 + j4);
-        }
+        fetch_signs(jj);
 #pragma unroll 1
-        for (int c = 0; c < kXgB / CR; ++c) {
-            __syncthreads();                                   // (the previous chunk is consumed)
+        while (jj >= 0) {
+            todo &= todo - 1u;
+            const int next = todo != 0u ? (int)__builtin_ctz(todo) : -1;
+            __syncthreads();                                   // (Ssl and Apan of the previous block consumed)
 #pragma unroll
-            for (int i = 0; i < CR / 4; ++i) *reinterpret_cast<f32x4acc *>(&Apan[4 * i + (tid >> 6)][4 * (tid & 63)]) = pre[i];
-            if (c + 1 < kXgB / CR) fetch_chunk(jj, c + 1);     // in flight under this chunk's MFMAs
-            __syncthreads();
-            if (wave_on) {
+            for (int i = 0; i < kXgB * kXgReps / 4 / 256; ++i) {
+                const int e = tid + 256 * i;
+                *reinterpret_cast<f32x4acc *>(&Ssl[e >> 4][(e & 15) * 4]) = spre[i];
+            }
+#pragma unroll 1
+            for (int c = 0; c < kXgB / CR; ++c) {
+                if (c > 0) __syncthreads();                    // (the previous chunk is consumed)
 #pragma unroll
-                for (int ks = 0; ks < CR / 4; ++ks) {          // k = CR c + 4 ks + lq
-                    float sa[4], qb[4];
+                for (int i = 0; i < CR / 4; ++i) *reinterpret_cast<f32x4acc *>(&Apan[4 * i + (tid >> 6)][4 * (tid & 63)]) = pre[i];
+                if (c + 1 < kXgB / CR) fetch_chunk(jj, c + 1);     // in flight under this chunk's MFMAs
+                else if (next >= 0) fetch_chunk(next, 0);
+                if (c == 1 && next >= 0) fetch_signs(next);
+                __syncthreads();
+                if (wave_on) {
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) sa[rt] = Ssl[CR * c + 4 * ks + lq][16 * rt + lr];        // A[i = lr][k = lq]
+                    for (int ks = 0; ks < CR / 4; ++ks) {          // k = CR c + 4 ks + lq
+                        float sa[4], qb[4];
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) qb[ct] = Apan[4 * ks + lq][64 * wave + 16 * ct + lr];    // B[k = lq][j = lr]
+                        for (int rt = 0; rt < 4; ++rt) sa[rt] = Ssl[CR * c + 4 * ks + lq][16 * rt + lr];        // A[i = lr][k = lq]
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
+                        for (int ct = 0; ct < 4; ++ct) qb[ct] = Apan[4 * ks + lq][64 * wave + 16 * ct + lr];    // B[k = lq][j = lr]
 #pragma unroll
-                        for (int rt = 0; rt < 4; ++rt)
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[rt], qb[ct], acc[rt][ct], 0, 0, 0);
+                        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                            for (int rt = 0; rt < 4; ++rt)
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[rt], qb[ct], acc[rt][ct], 0, 0, 0);
+                    }
                 }
             }
+            jj = next;
         }
     }
     if (wave_on) {
