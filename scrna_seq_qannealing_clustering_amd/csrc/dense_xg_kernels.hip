@@ -386,6 +386,8 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     const int col0 = MINI ? (kXgGrp * g + j + 1 + 4 * yy) * kXgB : cy * kXgCols;
     unsigned int live = 0;                                    // bit jj: block jj flipped a row in these 64 replicas
     for (int jj = jb0; jj < jb1; ++jj) live |= (a.flags[((size_t)par * kXgGrp + jj) * ranges + rx] != 0u ? 1u : 0u) << jj;
+    live = (unsigned int)__builtin_amdgcn_readfirstlane((int)live);   // (workgroup-uniform: keeps the block index, and with it the
+                                                                      // buffer descriptors below, in scalar registers)
     if (live == 0u && !(MINI && j == 0)) return;              // (the first MINI of a group also COPIES F into Tm)
     const bool wave_on = !MINI || 4 * yy + wave < nbg - 1 - j;   // MINI: one wave per later block of the group
 
@@ -397,7 +399,8 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     const int sq = (int)(4 * a.stride * 4);                  // four rows on: the soffset step of a thread's next piece
     auto fetch_chunk = [&](int jj, int c) {                   // rows 16 c .. 16 c + 15 of block kXgGrp g + jj, columns col0 ..
         const int row0 = (kXgGrp * g + jj) * kXgB + CR * c;
-        const int valid = a.n - row0 < 0 ? 0 : (a.n - row0 > CR ? CR : a.n - row0);
+        // (readfirstlane: hipcc clamps with a VECTOR med3, and a descriptor held in vector registers costs a waterfall loop per load)
+        const int valid = __builtin_amdgcn_readfirstlane(a.n - row0 < 0 ? 0 : (a.n - row0 > CR ? CR : a.n - row0));
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.Q2 + (size_t)row0 * a.stride + col0), 0, (int)((size_t)valid * a.stride * 4), 0x00020000);
 #pragma unroll
