@@ -256,6 +256,13 @@ def test_error_behaviour():
         p.anneal(2, [1.0, float("nan")], 1)
     with pytest.raises(ValueError):
         p.anneal(2, [1.0], 1, initial_states=np.zeros((3, 4)))
+    # options: unknown keys and values outside a key's range are refused, the setting stays what it was
+    for key, value in (("no_such_option", 1), ("xl_batched", 3), ("xl_chain", 3), ("xl_chain", -1), ("xl_chunk", 0),
+                       ("variant", 9)):
+        with pytest.raises(_lib.MiSaError):
+            p.set_option(key, value)
+    for key, value in (("xl_batched", 2), ("xl_chain", 2), ("xl_chain", 0), ("xl_chunk", 3), ("xl_cold_permille", 0)):
+        p.set_option(key, value)
     p.close()
     assert b"" == b"" and lib.mi_last_error() is not None
     # holes of a padded layout: only positions without couplings, only Potts problems (a binary CSR model marks its
