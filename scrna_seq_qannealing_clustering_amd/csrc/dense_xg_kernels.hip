@@ -201,8 +201,8 @@ __global__ void __launch_bounds__(256) k_xg_diag(XgArgs a, int b, int force, int
 // ---- CHAIN(g): the whole chain of a group in ONE launch, one workgroup per 64 replicas.  The DIAGs and small passes of
 // a group never leave their replica range: the fields of the group's later blocks (7 x 64 columns x 64 replicas) live
 // in LDS instead of Tm, DIAG(j) decides on them, and the rows of block j go onto the columns of blocks j + 1 .. by
-// chained MFMAs straight out of and back into LDS (wave w: later blocks j + 1 + w, j + 5 + w; the Q2 operands of a
-// wave's first later block are loaded BEFORE the 64 sequential decisions and arrive under them).  Same arithmetic
+// chained MFMAs straight out of and back into LDS (wave w: columns 16 w .. of every later block; its Q2 operands for
+// the first two later blocks are loaded BEFORE the 64 sequential decisions and arrive under them).  Same arithmetic
 // in the same order as k_xg_diag + k_xg_panel<true> (tests compare the two), 15 launches and their gaps fewer per
 // group: below 256 replicas the chain IS the run time.  Signs, state words and flags go to HBM as before (the
 // group's full pass reads them); thresholds come from k_xg_thresholds. ----
@@ -230,39 +230,64 @@ __global__ void __launch_bounds__(256, 1) k_xg_chain(XgArgs a, int g, int nbg, i
         }
     }
     unsigned long long accepted = 0;
+    // What a block's decisions need from HBM -- its coupling block, thresholds and state word -- is fetched one block ahead,
+    // under the decisions of the block before (a round trip to memory in front of every block's first decision otherwise).
+    auto load_ct = [&](f32x4acc (&dst)[4], int R0) {          // the 64 x 64 coupling block Q2[R0 ..][R0 ..]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, k = e >> 4, c = e & 15;
+            dst[i] = f32x4acc{0, 0, 0, 0};
+            if (R0 + k < a.n) dst[i] = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)(R0 + k) * a.stride + R0 + 4 * c);
+        }
+    };
+    auto store_ct = [&](const f32x4acc (&src)[4]) {            // Ct[k][q][m] = Q2[R0 + k][R0 + q + 4 m]: columns 4 c .. + 3 are q = 0..3 at m = c
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, k = e >> 4, c = e & 15;
+            Ct[k][0][c] = src[i][0]; Ct[k][1][c] = src[i][1]; Ct[k][2][c] = src[i][2]; Ct[k][3][c] = src[i][3];
+        }
+    };
+    f32x4acc ctn[4];
+    float th[16], thn[16];
+    f32x2 t[8];                                                // the lane's 16 fields as pairs: two row updates per v_pk_fma_f32
+    unsigned long long xw, xwn = 0;
+    {
+        const int b0 = kXgGrp * g;
+        load_ct(ctn, b0 * kXgB);
+        xw = a.XT[(size_t)b0 * a.Rp + r];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            th[m] = a.TH[((size_t)0 * 64 + q + 4 * m) * a.Rp + r];
+            t[m >> 1][m & 1] = a.F[fidx(a, b0 * kXgB + q + 4 * m, r)];
+        }
+        store_ct(ctn);
+    }
     for (int j = 0; j < nbg; ++j) {
         const int b = kXgGrp * g + j, R0 = b * kXgB;
         float *Sj = a.S + ((size_t)par * kXgGrp + j) * kXgB * a.Rp;
-        // operands of this wave's first later block (rows of block j, its 64 columns): in flight under the decisions
-        const int jb_first = j + 1 + wave;
-        float qpre[16][4];
-        if (jb_first < nbg) {
+        // small passes: wave w owns columns 16 w .. 16 w + 15 of EVERY later block (the same work for all four waves whatever
+        // the number of later blocks).  Its operands for the first two later blocks (rows of block j) are loaded here, in
+        // flight under the 64 decisions; the ones after arrive under the MFMAs of the block before.
+        float qa[16], qn[16];
+        auto load_q = [&](float (&dst)[16], int jb) {
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    const int row = R0 + 4 * ks + lq;
-                    qpre[ks][ct] = row < a.n ? a.Q2[(size_t)row * a.stride + (size_t)(kXgGrp * g + jb_first) * kXgB + 16 * ct + lr] : 0.0f;
-                }
-        }
-        for (int e = tid; e < kXgB * kXgB / 4; e += 256) {
-            const int k = e >> 4, c = e & 15;                             // columns R0 + 4 c .. + 3: q = 0..3 at m = c
-            f32x4acc v = {0, 0, 0, 0};
-            if (R0 + k < a.n) v = *reinterpret_cast<const f32x4acc *>(a.Q2 + (size_t)(R0 + k) * a.stride + R0 + 4 * c);
-            Ct[k][0][c] = v[0]; Ct[k][1][c] = v[1]; Ct[k][2][c] = v[2]; Ct[k][3][c] = v[3];
-        }
-        const unsigned long long xw = a.XT[(size_t)b * a.Rp + r];
-        float t[16], th[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) th[m] = a.TH[((size_t)j * 64 + q + 4 * m) * a.Rp + r];
-        if (j == 0) {
-#pragma unroll
-            for (int m = 0; m < 16; ++m) t[m] = a.F[fidx(a, R0 + q + 4 * m, r)];
-        }
+            for (int ks = 0; ks < 16; ++ks) {
+                const int row = R0 + 4 * ks + lq;
+                dst[ks] = row < a.n ? a.Q2[(size_t)row * a.stride + (size_t)(kXgGrp * g + jb) * kXgB + 16 * wave + lr] : 0.0f;
+            }
+        };
+        if (j + 1 < nbg) load_q(qa, j + 1);
+        if (j + 2 < nbg) load_q(qn, j + 2);
         __syncthreads();                                       // Ct staged; Fo carries the rows of blocks < j
         if (j > 0) {
 #pragma unroll
-            for (int m = 0; m < 16; ++m) t[m] = Fo[j - 1][q + 4 * m][rl];
+            for (int m = 0; m < 16; ++m) t[m >> 1][m & 1] = Fo[j - 1][q + 4 * m][rl];
+        }
+        if (j + 1 < nbg) {                                     // the next block's inputs, in flight under this block's decisions
+            load_ct(ctn, R0 + kXgB);
+            xwn = a.XT[(size_t)(b + 1) * a.Rp + r];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) thn[m] = a.TH[((size_t)(j + 1) * 64 + q + 4 * m) * a.Rp + r];
         }
         unsigned long long word = 0;
         bool any = false;
@@ -275,17 +300,19 @@ __global__ void __launch_bounds__(256, 1) k_xg_chain(XgArgs a, int g, int nbg, i
 #pragma unroll
             for (int g4 = mk >> 2; g4 < 4; ++g4) c4[g4] = *reinterpret_cast<const f32x4acc *>(&Ct[k][q][4 * g4]);
             const bool xk = ((xw >> k) & 1ull) != 0ull;
-            const float dE = xk ? -t[mk] : t[mk];
+            const float tk = t[mk >> 1][mk & 1];
+            const float dE = xk ? -tk : tk;
             const bool acc = (q == qk) && dE < th[mk];                    // the lane that holds row k
             const float so = acc ? (xk ? -1.0f : 1.0f) : 0.0f;
             const float sk = xg_quad_bcast<qk>(so);
             if (q == qk) Sl[k][rl] = so;
             if (acc) { word |= 1ull << k; ++accepted; }
             if (__ballot(acc) != 0ull) {                                  // (wave-uniform: nobody flipped row k)
+                const f32x2 s2 = {sk, sk};
 #pragma unroll
-                for (int g4 = mk >> 2; g4 < 4; ++g4) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) t[4 * g4 + i] = __fmaf_rn(c4[g4][i], sk, t[4 * g4 + i]);
+                for (int g4 = mk >> 2; g4 < 4; ++g4) {                    // (c * s + t per element, as __fmaf_rn(c, s, t))
+                    t[2 * g4 + 0] = __builtin_elementwise_fma(f32x2{c4[g4][0], c4[g4][1]}, s2, t[2 * g4 + 0]);
+                    t[2 * g4 + 1] = __builtin_elementwise_fma(f32x2{c4[g4][2], c4[g4][3]}, s2, t[2 * g4 + 1]);
                 }
                 any = any || acc;
             }
@@ -299,48 +326,43 @@ __global__ void __launch_bounds__(256, 1) k_xg_chain(XgArgs a, int g, int nbg, i
             if (q == 0) a.XT[(size_t)b * a.Rp + r] = xw ^ (((unsigned long long)hi << 32) | lo);
         }
         if (__ballot(any) != 0ull && lane == 0) atomicOr(&any_s[j], 1);
-        __syncthreads();                                       // signs in Sl, the block's flag complete
+        __syncthreads();                                       // signs in Sl, the block's flag complete; Ct is free
+        if (j + 1 < nbg) store_ct(ctn);
         for (int e = tid; e < kXgB * kXgReps / 4; e += 256) {  // ... and on their way to HBM for the group's full pass
             const int k = e >> 4, r4 = (e & 15) * 4;
             *reinterpret_cast<f32x4acc *>(Sj + (size_t)k * a.Rp + blockIdx.x * 64 + r4) = *reinterpret_cast<const f32x4acc *>(&Sl[k][r4]);
         }
         const bool live = any_s[j] != 0;
         if (tid == 0) a.flags[((size_t)par * kXgGrp + j) * ranges + blockIdx.x] = live ? 1u : 0u;
-        if (live) {
-            // rows of block j onto the columns of the later blocks: C[i = replica][j = column] tiles, chained in row order
-            for (int jb = jb_first; jb < nbg; jb += 4) {
-                if (jb != jb_first) {
+        if (live && j + 1 < nbg) {
+            // rows of block j onto the columns of the later blocks: C[i = replica][j = column] tiles of this wave's 16 columns,
+            // chained in row order; the signs (A operand) are the same for every later block
+            float sa[16][4];
 #pragma unroll
-                    for (int ks = 0; ks < 16; ++ks)
+            for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) {
-                            const int row = R0 + 4 * ks + lq;
-                            qpre[ks][ct] = row < a.n ? a.Q2[(size_t)row * a.stride + (size_t)(kXgGrp * g + jb) * kXgB + 16 * ct + lr] : 0.0f;
-                        }
-                }
-                f32x4acc acc[4][4];
+                for (int rt = 0; rt < 4; ++rt) sa[ks][rt] = Sl[4 * ks + lq][16 * rt + lr];                    // A[i = lr][k = lq]
+#pragma unroll 1
+            for (int jb = j + 1; jb < nbg; ++jb) {
+                f32x4acc acc[4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
+                for (int rt = 0; rt < 4; ++rt) acc[rt] = *reinterpret_cast<const f32x4acc *>(&Fo[jb - 1][16 * wave + lr][16 * rt + 4 * lq]);
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = *reinterpret_cast<const f32x4acc *>(&Fo[jb - 1][16 * ct + lr][16 * rt + 4 * lq]);
+                for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    float sa[4];
+                    for (int rt = 0; rt < 4; ++rt)
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[ks][rt], qa[ks], acc[rt], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) sa[rt] = Sl[4 * ks + lq][16 * rt + lr];                    // A[i = lr][k = lq]
+                for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4acc *>(&Fo[jb - 1][16 * wave + lr][16 * rt + 4 * lq]) = acc[rt];
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                        for (int rt = 0; rt < 4; ++rt)
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[rt], qpre[ks][ct], acc[rt][ct], 0, 0, 0);
-                }
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4acc *>(&Fo[jb - 1][16 * ct + lr][16 * rt + 4 * lq]) = acc[rt][ct];
+                for (int ks = 0; ks < 16; ++ks) qa[ks] = qn[ks];
+                if (jb + 2 < nbg) load_q(qn, jb + 2);
             }
         }
-        __syncthreads();                                       // Fo, Ct and Sl are free for the next block
+        __syncthreads();                                       // Fo and Sl are free for the next block, its Ct is in place
+        xw = xwn;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) th[m] = thn[m];
     }
     // accepted flips of this wavefront -> stats[1]
     unsigned long long tot = accepted;
