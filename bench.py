@@ -242,7 +242,7 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
                           "tflops": executed / (ms * 1e-3) / 1e12, "peak_tflops_f32_input_mfma": 157.3,
                           "frac_of_mfma_peak": executed / (ms * 1e-3) / 157.3e12,
                           "dense_equivalent_tflops": 2.0 * n * n * len(X) / (ms * 1e-3) / 1e12,
-                          "timed": "transpose of the states + fill + MFMA kernel (one call)",
+                          "timed": "transpose of the states + MFMA kernel (one call)",
                           "max_rel_diff_vs_exact_fp64": float(np.max(np.abs(e_mfma[:256] - e_exact) /
                                                                      np.maximum(1.0, np.abs(e_exact))))}
     if os.environ.get("MI_BENCH_SKIP_50K") != "1":

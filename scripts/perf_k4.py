@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""K4 (replica-batched energies on the matrix cores) alone: time of the whole call (transpose + fill + MFMA kernel) for
+"""K4 (replica-batched energies on the matrix cores) alone: time of the whole call (transpose + MFMA kernel) for
 R states of an n-variable dense model, and the deviation from the exact fp64 path (development helper).
 usage: perf_k4.py [--n 2638] [--states 4096]"""
 import argparse

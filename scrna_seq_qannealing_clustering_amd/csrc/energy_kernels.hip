@@ -39,11 +39,13 @@ __global__ void __launch_bounds__(256) k_energy_dense_valu(const QT *__restrict_
     if (lane == 0) out[r] = e + offset;
 }
 
-// X [R][n] (state-major bytes) -> Xt [n][Rpad] (variable-major, zero padded to a multiple of 128 states) and the same
-// states as BITS, Xm [n][Rpad / 32] (bit r & 31 of word r >> 5): 64 x 64 byte tiles through LDS, so both the reads
-// (along n) and the writes (along R) are contiguous.  Rows n .. n_pad of both stay zero (cleared by the caller).
+// X [R][n] (state-major bytes) -> Xt [n_pad][Rpad] (variable-major, zero padded to multiples of 128 both ways) and the same
+// states as BITS, Xm [n_pad][Rpad / 32] (bit r & 31 of word r >> 5): 64 x 64 byte tiles through LDS, so both the reads
+// (along n) and the writes (along R) are contiguous.  The grid covers the padded extent (the padding is written, not
+// cleared beforehand), and the first row of workgroups starts the energies at the model's offset.
 __global__ void __launch_bounds__(256) k_transpose_states(const uint8_t *__restrict__ X, int R, int n,
-                                                          uint8_t *__restrict__ Xt, unsigned int *__restrict__ Xm, int Rpad)
+                                                          uint8_t *__restrict__ Xt, unsigned int *__restrict__ Xm, int Rpad,
+                                                          double offset, double *__restrict__ out)
 {
     __shared__ unsigned char t[64][68];
     const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
@@ -53,22 +55,15 @@ __global__ void __launch_bounds__(256) k_transpose_states(const uint8_t *__restr
         const int r = r0 + row, k = k0 + seg + b;
         t[row][seg + b] = (r < R && k < n) ? X[(size_t)r * n + k] : (uint8_t)0;
     }
+    if (blockIdx.y == 0 && threadIdx.x < 64 && r0 + (int)threadIdx.x < R) out[r0 + threadIdx.x] = offset;
     __syncthreads();
     unsigned int bits = 0u;
 #pragma unroll
     for (int b = 0; b < 16; ++b) bits |= (unsigned int)(t[seg + b][row] & 1u) << b;
     const unsigned int other = __shfl_xor(bits, 1, 64);           // the neighbouring 16 states of the same variable
-    if (k0 + row < n) {
 #pragma unroll
-        for (int b = 0; b < 16; ++b) Xt[(size_t)(k0 + row) * Rpad + r0 + seg + b] = t[seg + b][row];
-        if ((threadIdx.x & 1) == 0) Xm[(size_t)(k0 + row) * (Rpad / 32) + (r0 + seg) / 32] = bits | (other << 16);
-    }
-}
-
-__global__ void __launch_bounds__(256) k_fill_f64(double *__restrict__ out, int R, double v)
-{
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < R) out[r] = v;
+    for (int b = 0; b < 16; ++b) Xt[(size_t)(k0 + row) * Rpad + r0 + seg + b] = t[seg + b][row];
+    if ((threadIdx.x & 1) == 0) Xm[(size_t)(k0 + row) * (Rpad / 32) + (r0 + seg) / 32] = bits | (other << 16);
 }
 
 // E_r = sum_{i,k} X_ir Qs_ik X_kr as an LDS-tiled f32 GEMM on the matrix cores, Y = Qs * X, fused with the masked
@@ -272,9 +267,7 @@ int mi_launch_energy_dense(const float *dQ, int n, int ldq, const uint8_t *dX, i
         const int T = (n + kGemmTile - 1) / kGemmTile;
         if (ldq != T * kGemmTile) return fail(MI_EINVAL, "MFMA energy path needs rows padded to %d floats", T * kGemmTile);
         unsigned int *dXm = reinterpret_cast<unsigned int *>(dXt + (size_t)ldq * Rpad);
-        HIP_TRY(hipMemsetAsync(dXt, 0, mi_energy_dense_scratch_bytes(n, R), st));
-        hipLaunchKernelGGL(k_transpose_states, dim3(Rpad / 64, (n + 63) / 64), dim3(256), 0, st, dX, R, n, dXt, dXm, Rpad);
-        hipLaunchKernelGGL(k_fill_f64, dim3((R + 255) / 256), dim3(256), 0, st, dE, R, offset);
+        hipLaunchKernelGGL(k_transpose_states, dim3(Rpad / 64, ldq / 64), dim3(256), 0, st, dX, R, n, dXt, dXm, Rpad, offset, dE);
         // pieces per state tile: the units should fill whole rounds of the resident workgroups (68 KB of LDS each: two
         // per CU) with pieces of (nearly) equal length
         int dev = 0, cus = 256;
