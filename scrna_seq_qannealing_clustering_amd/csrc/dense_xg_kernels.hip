@@ -380,9 +380,13 @@ __global__ void __launch_bounds__(256, 1) k_xg_chain(XgArgs a, int g, int nbg, i
 //                 untouched until the group's full pass, which applies the same rows in the same order.
 // The full pass of a group is launched in two parts: first the 256 columns that are the NEXT group's own (cy_only), then
 // the rest (cy_skip) -- the next group's DIAGs need only the first part and run beside the second (dense_xg host loop).
-template <bool MINI>
+// NCT = 16-column tiles per wave: 4 (a workgroup owns 256 columns) everywhere but in the first part of a full pass, whose
+// few workgroups sit on the critical path of the next group's chain -- there 1 (64 columns per workgroup, four times
+// the workgroups, a quarter of the matrix work each).
+template <bool MINI, int NCT>
 __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, int j, int par, int cy_only, int cy_skip)
 {
+    constexpr int CW = 16 * NCT;                              // columns per wave
     constexpr int AS = kXgCols + 16, SS = kXgReps + 16;       // padded LDS strides: conflict-free operand reads
     constexpr int CR = 16;                                    // rows of Q2 per chunk in LDS (the next chunk waits in registers)
     __shared__ __attribute__((aligned(16))) float Apan[CR][AS];
@@ -397,7 +401,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
         tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + tile / 8;
     }
     const int rx = tile % (int)gridDim.x, ty = tile / (int)gridDim.x;
-    const int cy = cy_only >= 0 ? cy_only + ty : ty;
+    const int cy = cy_only >= 0 ? cy_only + ty / (4 / NCT) : ty;     // (NCT = 1: four workgroups per 256 columns)
     if (!MINI && cy_skip >= 0 && cy >= cy_skip && cy < cy_skip + kXgGrp / 4) return;
     const int yy = MINI ? ty : 0;                             // MINI: which four of the later blocks
     const int tid = threadIdx.x, lane = tid & 63;
@@ -405,7 +409,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     const int lr = lane & 15, lq = lane >> 4;
     const int rep0 = rx * kXgReps;
     const int jb0 = MINI ? j : 0, jb1 = MINI ? j + 1 : nbg;   // row blocks of the group this pass applies
-    const int col0 = MINI ? (kXgGrp * g + j + 1 + 4 * yy) * kXgB : cy * kXgCols;
+    const int col0 = MINI ? (kXgGrp * g + j + 1 + 4 * yy) * kXgB : cy * kXgCols + (NCT == 1 ? 64 * (ty % 4) : 0);
     unsigned int live = 0;                                    // bit jj: block jj flipped a row in these 64 replicas
     for (int jj = jb0; jj < jb1; ++jj) live |= (a.flags[((size_t)par * kXgGrp + jj) * ranges + rx] != 0u ? 1u : 0u) << jj;
     live = (unsigned int)__builtin_amdgcn_readfirstlane((int)live);   // (workgroup-uniform: keeps the block index, and with it the
@@ -416,8 +420,9 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     // chunk and sign loads through buffer descriptors with a UNIFORM base per chunk / block (scalar arithmetic) and
     // per-thread offsets that never change -- no 64-bit address arithmetic in vector registers (the kernel lives on 128
     // of them); rows past n are outside the descriptor and read as zero
-    f32x4acc pre[CR / 4];
-    const int vq = (int)(((size_t)(tid >> 6) * a.stride + 4 * (tid & 63)) * 4);
+    f32x4acc pre[NCT];                                        // 16 rows x 64 NCT columns: NCT pieces of 16 bytes per thread
+    const int prow = NCT == 4 ? tid >> 6 : tid >> 4, pcol = NCT == 4 ? 4 * (tid & 63) : 4 * (tid & 15);
+    const int vq = (int)(((size_t)prow * a.stride + pcol) * 4);
     const int sq = (int)(4 * a.stride * 4);                  // four rows on: the soffset step of a thread's next piece
     auto fetch_chunk = [&](int jj, int c) {                   // rows 16 c .. 16 c + 15 of block kXgGrp g + jj, columns col0 ..
         const int row0 = (kXgGrp * g + jj) * kXgB + CR * c;
@@ -426,22 +431,22 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.Q2 + (size_t)row0 * a.stride + col0), 0, (int)((size_t)valid * a.stride * 4), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < CR / 4; ++i)
+        for (int i = 0; i < NCT; ++i)
             pre[i] = __builtin_bit_cast(f32x4acc, __builtin_amdgcn_raw_buffer_load_b128(rq, vq, i * sq, 0));
     };
-    // accumulators: tile (rt, ct): replicas rep0 + 16 rt + 4 lq + reg, column 64 wave + 16 ct + lr of the workgroup's 256
+    // accumulators: tile (rt, ct): replicas rep0 + 16 rt + 4 lq + reg, column CW wave + 16 ct + lr of the workgroup's 64 NCT
     auto field_ptr = [&](bool dst, int ct, int rt) -> float * {
         const int r = rep0 + 16 * rt + 4 * lq;
         if (MINI) {
-            if (!dst && j == 0) return a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, r);
+            if (!dst && j == 0) return a.F + fidx(a, col0 + CW * wave + 16 * ct + lr, r);
             return a.Tm + tmidx(j + 4 * yy + wave, 16 * ct + lr, r);
         }
-        return a.F + fidx(a, col0 + 64 * wave + 16 * ct + lr, r);
+        return a.F + fidx(a, col0 + CW * wave + 16 * ct + lr, r);
     };
-    f32x4acc acc[4][4];
+    f32x4acc acc[4][NCT];
     if (wave_on) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = *reinterpret_cast<const f32x4acc *>(field_ptr(false, ct, rt));
     }
@@ -477,7 +482,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
             for (int c = 0; c < kXgB / CR; ++c) {
                 if (c > 0) __syncthreads();                    // (the previous chunk is consumed)
 #pragma unroll
-                for (int i = 0; i < CR / 4; ++i) *reinterpret_cast<f32x4acc *>(&Apan[4 * i + (tid >> 6)][4 * (tid & 63)]) = pre[i];
+                for (int i = 0; i < NCT; ++i) *reinterpret_cast<f32x4acc *>(&Apan[4 * i + prow][pcol]) = pre[i];
                 if (c + 1 < kXgB / CR) fetch_chunk(jj, c + 1);     // in flight under this chunk's MFMAs
                 else if (next >= 0) fetch_chunk(next, 0);
                 if (c == 1 && next >= 0) fetch_signs(next);
@@ -485,13 +490,13 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
                 if (wave_on) {
 #pragma unroll
                     for (int ks = 0; ks < CR / 4; ++ks) {          // k = CR c + 4 ks + lq
-                        float sa[4], qb[4];
+                        float sa[4], qb[NCT];
 #pragma unroll
                         for (int rt = 0; rt < 4; ++rt) sa[rt] = Ssl[CR * c + 4 * ks + lq][16 * rt + lr];        // A[i = lr][k = lq]
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) qb[ct] = Apan[4 * ks + lq][64 * wave + 16 * ct + lr];    // B[k = lq][j = lr]
+                        for (int ct = 0; ct < NCT; ++ct) qb[ct] = Apan[4 * ks + lq][CW * wave + 16 * ct + lr];  // B[k = lq][j = lr]
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct)
+                        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                             for (int rt = 0; rt < 4; ++rt)
                                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[rt], qb[ct], acc[rt][ct], 0, 0, 0);
@@ -503,7 +508,7 @@ __global__ void __launch_bounds__(256, 4) k_xg_panel(XgArgs a, int g, int nbg, i
     }
     if (wave_on) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4acc *>(field_ptr(true, ct, rt)) = acc[rt][ct];
     }
@@ -680,7 +685,7 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
                 for (int j = 0; j < nbg; ++j) {
                     hipLaunchKernelGGL(k_xg_diag, gdiag, dim3(256), 0, sb, a, kXgGrp * g + j, ps.force, par);
                     if (!ps.force && j + 1 < nbg)
-                        hipLaunchKernelGGL(k_xg_panel<true>, dim3(a.Rp / kXgReps, (nbg - 1 - j + 3) / 4), dim3(256), 0, sb, a, g, nbg, j, par, -1, -1);
+                        hipLaunchKernelGGL((k_xg_panel<true, 4>), dim3(a.Rp / kXgReps, (nbg - 1 - j + 3) / 4), dim3(256), 0, sb, a, g, nbg, j, par, -1, -1);
                 }
             }
             HIP_TRY(hipEventRecord(evS[G & 3], sb));
@@ -693,10 +698,10 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
                 if (G >= 1) HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 1) & 3], 0));
                 const int cyn = gn * (kXgGrp / 4);                 // the next group's columns: kXgGrp / 4 workgroup ranges
                 const int ncy = (a.ncols / kXgCols - cyn) < kXgGrp / 4 ? (a.ncols / kXgCols - cyn) : kXgGrp / 4;
-                hipLaunchKernelGGL(k_xg_panel<false>, dim3(a.Rp / kXgReps, ncy), dim3(256), 0, sb, a, g, nbg, 0, par, cyn, -1);
-                hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, cyn);
+                hipLaunchKernelGGL((k_xg_panel<false, 1>), dim3(a.Rp / kXgReps, 4 * ncy), dim3(256), 0, sb, a, g, nbg, 0, par, cyn, -1);
+                hipLaunchKernelGGL((k_xg_panel<false, 4>), gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, cyn);
             } else {
-                hipLaunchKernelGGL(k_xg_panel<false>, gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, -1);
+                hipLaunchKernelGGL((k_xg_panel<false, 4>), gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, -1);
             }
             HIP_TRY(hipEventRecord(evP[G & 3], sa));
         }
