@@ -226,8 +226,10 @@ int mi_sa_qubo_dense_f32(const float *Qs, int n, double offset, int R, int num_s
 /* Batched energy evaluation E_r = x_r^T Qs x_r + offset for R states (K4).  Serves SampleSet energy
  * re-evaluation (BQM_clustering.py:93-98, :133-146 read these energies).  path: 0 = auto (f32-input MFMA
  * when the batch is >= 32 states wide, i.e. a true dense contraction; exact-fp64 VALU otherwise),
- * 1 = VALU (every fp32 entry added once into fp64), 2 = MFMA (fp32 partial sums of <= 32 terms folded
- * into fp64: ~1e-7 of sum|terms|).  out_kernel_ms (nullable): device time of the evaluation kernels. */
+ * 1 = VALU (every fp32 entry added once into fp64), 2 = MFMA (Qs SYMMETRIC, as everywhere in this header: only the
+ * 128 x 128 blocks on and above the diagonal are multiplied, an off-diagonal block counts twice; fp32 partial
+ * sums of <= 128 terms folded into fp64: ~1e-7 of sum|terms|).  out_kernel_ms (nullable): device time of the
+ * evaluation kernels. */
 int mi_energy_dense_f32(const float *Qs, int n, const uint8_t *X, int R, double offset,
                         double *out_energy, int device);
 /* The same evaluation over an fp64 matrix (the caller's own coefficients, every entry added once into fp64):
