@@ -698,7 +698,10 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
                 if (G >= 1) HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 1) & 3], 0));
                 const int cyn = gn * (kXgGrp / 4);                 // the next group's columns: kXgGrp / 4 workgroup ranges
                 const int ncy = (a.ncols / kXgCols - cyn) < kXgGrp / 4 ? (a.ncols / kXgCols - cyn) : kXgGrp / 4;
-                hipLaunchKernelGGL((k_xg_panel<false, 1>), dim3(a.Rp / kXgReps, 4 * ncy), dim3(256), 0, sb, a, g, nbg, 0, par, cyn, -1);
+                // (64-column workgroups where this part is on the critical path -- few replica ranges, the fused chain; with many
+                // ranges it hides behind the full pass and its 8 CUs are better off with a quarter of the workgroups)
+                if (fused) hipLaunchKernelGGL((k_xg_panel<false, 1>), dim3(a.Rp / kXgReps, 4 * ncy), dim3(256), 0, sb, a, g, nbg, 0, par, cyn, -1);
+                else hipLaunchKernelGGL((k_xg_panel<false, 4>), dim3(a.Rp / kXgReps, ncy), dim3(256), 0, sb, a, g, nbg, 0, par, cyn, -1);
                 hipLaunchKernelGGL((k_xg_panel<false, 4>), gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, cyn);
             } else {
                 hipLaunchKernelGGL((k_xg_panel<false, 4>), gpanel, dim3(256), 0, sa, a, g, nbg, 0, par, -1, -1);
