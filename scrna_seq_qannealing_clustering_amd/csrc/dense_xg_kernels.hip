@@ -95,9 +95,11 @@ __global__ void __launch_bounds__(256) k_xg_fill_fields(XgArgs a)
     if (idx < (size_t)a.ncols * a.Rp) a.F[idx] = a.diag[(idx >> 6) % (size_t)a.ncols];
 }
 
-// thresholds of blocks 4 tg .. 4 tg + 3 for sweep s: TH[c][lane][r] = -ln(u) * T   (-inf: no such variable / replica)
-__global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg, uint32_t sweep, int s_local, int slot0)
+// thresholds of blocks 4 tg .. 4 tg + 3 for sweep s: TH[c][lane][r] = -ln(u) * T   (-inf: no such variable / replica);
+// blockIdx.z = which four of the group's blocks (one launch per group)
+__global__ void __launch_bounds__(256) k_xg_thresholds(XgArgs a, int tg0, uint32_t sweep, int s_local)
 {
+    const int tg = tg0 + (int)blockIdx.z, slot0 = 4 * (int)blockIdx.z;
     const int r = blockIdx.x * 256 + threadIdx.x, lane = blockIdx.y;
     if (r >= a.Rp) return;
     float th[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -677,8 +679,8 @@ int mi_launch_dense_xg(const DenseXlArgs &x, int chunks, void *workspace, hipStr
             if (!ps.force && G >= 1 && !split_prev)                                   // its own columns of F are final: the
                 HIP_TRY(hipStreamWaitEvent(sb, evP[(G - 1) & 3], 0));                 // previous full pass (or its first part, on B)
             if (!ps.force)
-                for (int h = 0; 4 * h < nbg; ++h)
-                    hipLaunchKernelGGL(k_xg_thresholds, gthr, dim3(256), 0, sb, a, g * (kXgGrp / 4) + h, ps.sweep, ps.s_local, 4 * h);
+                hipLaunchKernelGGL(k_xg_thresholds, dim3(gthr.x, gthr.y, (nbg + 3) / 4), dim3(256), 0, sb, a, g * (kXgGrp / 4), ps.sweep,
+                                   ps.s_local);
             if (fused && !ps.force) {
                 hipLaunchKernelGGL(k_xg_chain, gdiag, dim3(256), 0, sb, a, g, nbg, par);
             } else {
