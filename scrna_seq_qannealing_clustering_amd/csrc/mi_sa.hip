@@ -514,7 +514,9 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
                 for (int t = 0; t < slots; ++t)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int k = 0; k < D; ++k)
-                            ha[(((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3)] = 4u * hc[((size_t)t * D + k) * 64 + lane];
+                            ha[(((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3)] =
+                                getenv("MI_K2_DEBUG_LINEAR") ? (uint32_t)(lane * 4 + (k * 256) % (slots * 256))   // TIMING ONLY: conflict-free gathers
+                                                             : 4u * hc[((size_t)t * D + k) * 64 + lane];
                 HIP_TRY(hipMalloc((void **)&p->d_adj4p, ha.size() * sizeof(uint32_t)));
                 HIP_TRY(hipMemcpy(p->d_adj4p, ha.data(), ha.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             }
