@@ -13,7 +13,8 @@ the CSR rows).  The dense form (K1w, 27.8 MB fp32 Q) and the Potts kernel run be
 
 Multi-GPU: replicas shard (weak scaling: 4096 replicas per GPU, global ids rank*4096..), the model is
 replicated, and each step ends with the ONE exchange the path has: a 64-bit MIN all-reduce of the
-packed (energy, replica id) key + a broadcast of the winner's labels (RCCL over xGMI).
+packed (fp64 energy, replica id) key + a broadcast of the winner's labels (RCCL over xGMI).
+`python bench.py --gpus N` typed without a launcher starts the N ranks itself, as child processes.
 
 Rank 0 prints one JSON line.  The model (0.34 MB in CSR form) lives in the L2s, never in HBM traffic terms, so the
 `roofline` object of the CSR kernel is an L2 roofline: `achieved` = bytes the kernel's loads request from L2
@@ -49,8 +50,9 @@ L2_PEAK_GBPS = 34500.0          # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s (
 
 def build_workload():
     from scrna_seq_qannealing_clustering_amd import graphs, models
-    nodes, eu, ev, w, _ = graphs.synthetic_snn(N_CELLS, K_NN, DIM, ORD, N_CLUSTERS, seed=0, spread=SPREAD)
+    nodes, eu, ev, w, truth = graphs.synthetic_snn(N_CELLS, K_NN, DIM, ORD, N_CLUSTERS, seed=0, spread=SPREAD)
     G = graphs.EdgeListGraph(nodes, eu, ev, w)
+    G.truth = truth                                  # planted cluster of every cell (reads_500 cuts a subgraph out)
     m = models.build_bqm_qubo(G, 0.05, k=8)
     Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))
     betas = models.make_beta_schedule(SWEEPS, models.default_beta_range(m))
@@ -81,14 +83,52 @@ def real_neal_probe(Qs, betas):
             "best_energy": float(ss.first.energy), "sample": "real dwave-neal, 4 reads x %d sweeps, same Q" % sweeps}
 
 
-def cpu_baseline(m, Qs, betas, edges, gpu_states, gpu_energies, perm, seconds_target=12.0):
+def wilson_interval(hits, n, z=1.96):
+    """95 % Wilson score interval of a binomial share."""
+    if n == 0:
+        return [0.0, 1.0]
+    ph = hits / n
+    den = 1.0 + z * z / n
+    mid = (ph + z * z / (2 * n)) / den
+    half = z * np.sqrt(ph * (1 - ph) / n + z * z / (4.0 * n * n)) / den
+    return [float(max(0.0, mid - half)), float(min(1.0, mid + half))]
+
+
+def equal_reads_stats(e_neal, e_gpu, best_known):
+    """Two samplers at EQUAL reads and sweeps, as distributions: share of the reads that end at the best energy known for
+    the model (`hit`, within 1e-9 relative) with 95 % Wilson bounds, mean +- standard error, and the two differences in
+    units of their standard errors.  Both chains are Metropolis sweeps over the same schedule: neither is expected to be
+    lower; which best-of-N wins in one run is chance."""
+    e_neal, e_gpu = np.asarray(e_neal, dtype=np.float64), np.asarray(e_gpu, dtype=np.float64)
+    tol = 1e-9 * abs(best_known)
+    out = {}
+    for name, e in (("neal", e_neal), ("gpu", e_gpu)):
+        hits = int(np.sum(e <= best_known + tol))
+        out[name] = {"reads": int(len(e)), "best_energy": float(e.min()), "mean_energy": float(e.mean()),
+                     "mean_standard_error": float(e.std(ddof=1) / np.sqrt(len(e))),
+                     "hits_at_best_known": hits, "hit_rate": hits / len(e), "hit_rate_95": wilson_interval(hits, len(e))}
+    pn, pg = out["neal"]["hit_rate"], out["gpu"]["hit_rate"]
+    pool = (out["neal"]["hits_at_best_known"] + out["gpu"]["hits_at_best_known"]) / (len(e_neal) + len(e_gpu))
+    se_hit = float(np.sqrt(max(pool * (1 - pool), 1e-12) * (1.0 / len(e_neal) + 1.0 / len(e_gpu))))
+    se_mean = float(np.hypot(out["neal"]["mean_standard_error"], out["gpu"]["mean_standard_error"]))
+    out["best_known_energy"] = float(best_known)
+    out["hit_rate_difference_sigmas"] = float((pg - pn) / se_hit)
+    out["mean_difference_standard_errors"] = float((out["gpu"]["mean_energy"] - out["neal"]["mean_energy"]) / se_mean)
+    return out
+
+
+EQUAL_READS = 256           # reads on both sides of the equal-reads comparison (neal restatement: ~23 s on 16 cores)
+
+
+def cpu_baseline(m, Qs, betas, edges, eq_gpu_states, eq_gpu_energies, best_known, perm, seconds_target=12.0):
     """The oracle on this host, on BOUNDED samples of the same workload:
       value        the restatement of dwave-neal (fp64 Ising, xorshift128+, dense couplings as neal's adjacency
                    lists would hold this QUBO, sequential sweeps) -- every (len/sweeps)-th beta of the schedule;
       same_chain   the chain the GPU kernel runs (CSR + uniform pair term, fp32, Philox: oracle 2b) on the same
                    threads -- the like-for-like algorithm (O(deg) per update instead of neal's O(n) per accepted flip);
-      equal_reads  neal restatement, 64 reads x the FULL schedule, against replicas 0..63 of the GPU run: best /
-                   mean energy (fp64, the caller's model) and the integer edge cut of the best state."""
+      equal_reads  neal restatement, EQUAL_READS reads x the FULL schedule (seed SEED + 1), against GPU replicas
+                   0 .. EQUAL_READS - 1 of seed SEED (`eq_gpu_*`: annealed once more for this, whatever --steps /
+                   --warmup were): hit rates at the best energy known, means, best cuts (equal_reads_stats)."""
     from oracle import sa_oracle as so
     eu, ev = edges
     h, J, off = so.qubo_to_ising_dense(Qs.astype(np.float64))
@@ -119,15 +159,23 @@ def cpu_baseline(m, Qs, betas, edges, gpu_states, gpu_energies, perm, seconds_ta
     sc_st, sc_en, sc_stats = so.sa_csr_rank1_philox(rp, cc, vv, lin, float(np.float32(m.c_pair)), sc_reads, sc_sub, SEED)
     t_sc = time.perf_counter() - t0
     # equal reads, equal sweeps
-    R_eq = 64
+    R_eq = len(eq_gpu_energies)
     t0 = time.perf_counter()
     sp, _, _ = so.sa_ising_neal_dense(h, J, R_eq, betas, seed=SEED + 1, threads=cores)
     t_eq = time.perf_counter() - t0
     xn = ((sp + 1) // 2).astype(np.uint8)
     e_neal = m.energies(xn)
-    cut_neal = so.cut_edges(eu, ev, xn)
-    e_gpu = np.asarray(gpu_energies[:R_eq])
-    cut_gpu = so.cut_edges(eu, ev, np.ascontiguousarray(gpu_states[:R_eq]))
+    e_gpu = np.asarray(eq_gpu_energies)
+    known = min(float(best_known), float(e_neal.min()), float(e_gpu.min()))
+    eq = equal_reads_stats(e_neal, e_gpu, known)
+    eq["neal"]["best_cut_edges"] = int(so.cut_edges(eu, ev, xn[int(np.argmin(e_neal))][None, :])[0])
+    eq["gpu"]["best_cut_edges"] = int(so.cut_edges(eu, ev, np.ascontiguousarray(eq_gpu_states[int(np.argmin(e_gpu))])[None, :])[0])
+    eq.update({"reads": R_eq, "sweeps": int(len(betas)), "seconds": t_eq,
+               "seeds": {"neal": SEED + 1, "gpu": SEED, "gpu_replicas": "0..%d" % (R_eq - 1)},
+               "note": "same schedule, same number of reads and sweeps; both chains are Metropolis sweeps (the same "
+                       "stationary distributions), so the two are statistically indistinguishable: hit rates at the best "
+                       "known energy within their binomial bounds, means within their standard errors "
+                       "(tests/test_gpu_sampler.py asserts 3 sigma / 4 s.e.); which best-of-%d is lower in one run is chance" % R_eq})
     return {
         "value": float(st[0]) / t, "unit": "spin-flip updates/s", "cores": cores, "kind": "port",
         "single_thread_value": single,
@@ -140,15 +188,7 @@ def cpu_baseline(m, Qs, betas, edges, gpu_states, gpu_energies, perm, seconds_ta
                        "best_energy": float(sc_en.min()), "seconds": t_sc,
                        "sample": "oracle 2b (the GPU kernel's chain: CSR + uniform pair, fp32, Philox), %d reads x %d sweeps "
                                  "(every 10th beta), OpenMP over reads" % (sc_reads, len(sc_sub))},
-        "equal_reads": {"reads": R_eq, "sweeps": int(len(betas)), "seconds": t_eq,
-                        "neal_best_energy": float(e_neal.min()), "neal_mean_energy": float(e_neal.mean()),
-                        "neal_best_cut_edges": int(cut_neal[int(np.argmin(e_neal))]),
-                        "gpu_best_energy": float(e_gpu.min()), "gpu_mean_energy": float(e_gpu.mean()),
-                        "gpu_best_cut_edges": int(cut_gpu[int(np.argmin(e_gpu))]),
-                        "gpu_all_replicas_best_energy": float(np.min(gpu_energies)),
-                        "note": "same schedule, same number of reads and sweeps; the two chains have the same stationary "
-                                "distributions (Metropolis, sequential sweeps), so which best-of-64 is lower is chance; the "
-                                "means agree within their standard errors (tests/test_gpu_sampler.py)"},
+        "equal_reads": eq,
         "real_neal": real_neal_probe(Qs, betas),         # null: not importable on this host
     }
 
@@ -206,7 +246,7 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
         name = "dense_bqm"
     else:
         p = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                              float(np.float32(m.c_pair)), device=rank_device, order="slots")
+                              float(np.float32(m.c_pair)), device=rank_device, order="padded")
         name = "csr_rank1_bqm"
     with p:
         p.anneal(R, b, SEED)
@@ -218,7 +258,7 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
                      "acceptance": info["accepted"] / info["proposals"]}
     pm = models.build_dqm_potts(graph, 8, 0.005)
     with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(np.float32), float(np.float32(pm.c_pair)), n, 8,
-                           lin_offset=pm.lin_offset, device=rank_device, order="slots") as p:
+                           lin_offset=pm.lin_offset, device=rank_device, order="padded") as p:
         b = models.make_beta_schedule(S, default_potts_beta_range(pm))
         p.anneal(R, b, SEED)
         ms = p.kernel_ms()
@@ -245,9 +285,51 @@ def other_kernels(m, Qs, betas, graph, rank_device, headline):
                           "timed": "transpose of the states + MFMA kernel (one call)",
                           "max_rel_diff_vs_exact_fp64": float(np.max(np.abs(e_mfma[:256] - e_exact) /
                                                                      np.maximum(1.0, np.abs(e_exact))))}
+    out["reads_500"] = reads_500(m, graph, rank_device)
     if os.environ.get("MI_BENCH_SKIP_50K") != "1":
         out["dense_xl_50k"] = dense_xl_50k(rank_device)
     return out
+
+
+def reads_500(m, graph, rank_device, reads=500, sweeps=1000):
+    """The reference's own call shape: `num_reads = 500` (BQM_clustering.py:52; 5000 at :240) x 1000 sweeps, on the whole
+    graph and on a subgraph of the size its recursive bisection reaches (:113-203; here the cells of one planted
+    cluster, n ~ 340).  500 reads are far fewer wavefronts than the chip has SIMDs (1024): the kernel time is one
+    wavefront's latency through the sweeps, not throughput."""
+    from scrna_seq_qannealing_clustering_amd import graphs, models
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    out = {"reads": reads, "sweeps": sweeps, "simds": 1024}
+    keep = np.flatnonzero(graph.truth == 3)
+    new_id = -np.ones(len(graph.truth), dtype=np.int64)
+    new_id[keep] = np.arange(len(keep))
+    eu, ev, w = graph._eu, graph._ev, graph._w
+    inside = (new_id[eu] >= 0) & (new_id[ev] >= 0)
+    sub = graphs.EdgeListGraph([str(i) for i in range(len(keep))], new_id[eu[inside]].astype(np.int32),
+                               new_id[ev[inside]].astype(np.int32), w[inside])
+    for name, mm in (("whole_graph", m), ("bisection_subgraph", models.build_bqm_qubo(sub, 0.05, k=8))):
+        nn = mm.num_variables
+        b = models.make_beta_schedule(sweeps, models.default_beta_range(mm))
+        with Problem.csr_rank1(mm.rowptr, mm.col, mm.val.astype(np.float32), mm.lin.astype(np.float32),
+                               float(np.float32(mm.c_pair)), device=rank_device, order="padded",
+                               energy_model=(mm.val, mm.lin, mm.c_pair)) as p:
+            p.anneal(reads, b, SEED)                                                   # warm (first launch of this shape)
+            p.anneal(reads, b, SEED)
+            ms, kname, slots = p.kernel_ms(), p.kernel_name(), p.n_dev // 64
+        waves = reads_wavefronts(kname, reads)
+        out[name] = {"n": nn, "device_slots": slots, "kernel": kname, "kernel_ms": ms,
+                     "updates_per_s": reads * sweeps * nn / (ms * 1e-3), "wavefronts": waves,
+                     "wavefronts_per_simd": waves / 1024.0}
+    return out
+
+
+def reads_wavefronts(kernel, reads):
+    """Wavefronts a run of `reads` replicas puts on the chip: the pair kernel carries two replicas per wavefront, the
+    split kernel (few reads: the idle SIMDs take a share of every replica's variables) several wavefronts per replica."""
+    import re
+    if "pair" in kernel:
+        return (reads + 1) // 2
+    mt = re.search(r"split<\d+,\s*(\d+)>", kernel)
+    return reads * int(mt.group(1)) if mt else reads
 
 
 def dense_xl_50k(rank_device, n=50000, replicas=1024, sweeps=4):
@@ -306,7 +388,7 @@ def dense_xl_50k(rank_device, n=50000, replicas=1024, sweeps=4):
             "host_build_s": t_build, "upload_s": t_upload, "best_energy": float(en.min())}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -316,7 +398,44 @@ def main():
     ap.add_argument("--kernel", choices=("csr", "dense"), default="csr",
                     help="timed kernel: csr = K2 (what the sampler runs for this model), dense = K1w")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_launch_command(args, argv, port=None):
+    """`python bench.py --gpus N` typed WITHOUT a launcher: the command that starts the N ranks (one per GPU) as
+    CHILD processes -- torch.distributed.run on this same file with the same arguments.  None when this process
+    already is a rank (WORLD_SIZE set by a launcher) or N = 1."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(cmd):
+    """Runs the rank processes as children of this one (which has not touched the GPU: nothing above imports torch or
+    loads the HIP library -- a process that has may not be replaced or re-exec'd on this pool), relays rank 0's JSON
+    line and returns the children's exit code."""
+    import subprocess
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def main():
+    args = parse_args()
+    cmd = rank_launch_command(args, sys.argv[1:])
+    if cmd is not None:
+        raise SystemExit(launch_ranks(cmd))
 
     import torch
     import torch.distributed as dist
@@ -348,8 +467,8 @@ def main():
         layout = "dense fp32 Q 27.8 MB"
     else:
         prob = Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                                 float(np.float32(m.c_pair)), device=local, order="slots",
-                                 energy_model=(m.val, m.lin, m.c_pair))               # as the sampler does
+                                 float(np.float32(m.c_pair)), device=local, order="padded",
+                                 energy_model=(m.val, m.lin, m.c_pair))               # exactly as sampler.py creates it
         bytes_per_update = 8.0 * float(np.diff(m.rowptr).mean()) + 8.0      # deg_i*(4+4) + 8
         layout = "CSR (cut term) + uniform pair term, %.1f neighbours per cell on average" % float(np.diff(m.rowptr).mean())
 
@@ -357,8 +476,8 @@ def main():
 
     def step(i):
         prob.anneal(R, betas, SEED + i, replica_offset=rank * R)
-        idx, e, key, state = prob.best()                           # K5 on device; waits for the anneal
-        return D.global_best(key, state, num_reads=world * R)      # C1 + C2 (identity at N=1)
+        idx, e, key, state = prob.best()                           # K5 on device (exact fp64 argmin); waits for the anneal
+        return D.global_best_f64(e, rank * R + idx, state, num_reads=world * R)    # C1 + C2 (identity at N=1)
 
     def fence():
         torch.cuda.synchronize()
@@ -387,6 +506,12 @@ def main():
     t_f0 = time.perf_counter()
     states, en, info = prob.fetch()
     fetch_ms = (time.perf_counter() - t_f0) * 1e3                  # R x n state bytes + R energies -> host
+    eq_states = eq_en = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the GPU side of cpu_baseline.equal_reads: replicas 0 .. EQUAL_READS - 1 of seed SEED over the full schedule,
+        # whatever --steps / --warmup / --replicas were (a replica's chain depends on (seed, global id) only)
+        prob.anneal(EQUAL_READS, betas, SEED)
+        eq_states, eq_en, _ = prob.fetch()
     updates_per_step = world * R * len(betas) * n
     value = updates_per_step * args.steps / elapsed
     k_ms = float(np.mean(kernel_ms))                               # all launches of one step
@@ -412,7 +537,7 @@ def main():
                              "step, K1w's sweeps included; K1m alone: 0.49 of the peak (profiles/r02_k1m_binding.json)"}
     else:
         ell_width = 16 if np.diff(m.rowptr).max() <= 16 else (32 if np.diff(m.rowptr).max() <= 32 else 64)
-        l2_bytes = l2_request_bytes_per_launch(kernel_name, R, sweeps_per_launch, n, ell_width)
+        l2_bytes = l2_request_bytes_per_launch(kernel_name, R, sweeps_per_launch, prob.n_dev, ell_width)
         l2_gbps = l2_bytes / (launch_ms * 1e-3) / 1e9
         roofline = {"bound": "l2", "achieved": l2_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": l2_gbps / L2_PEAK_GBPS,
                     "traffic": pmc_traffic(R, len(betas), launches, kernel_name),
@@ -435,7 +560,7 @@ def main():
                                "(gamma_factor 0.05, k 8), %s, resident in HBM, %d replicas/GPU x %d sweeps, "
                                "geometric beta, seed 1234" % (layout, R, len(betas)),
                    "kernel": args.kernel,
-                   "n": n, "replicas_per_gpu": R, "sweeps": int(len(betas)), "parallelism": "replicas sharded x%d" % world},
+                   "n": n, "device_slots": prob.n_dev // 64 if args.kernel == "csr" else None, "replicas_per_gpu": R, "sweeps": int(len(betas)), "parallelism": "replicas sharded x%d" % world},
         "roofline": roofline,
         "effective": {"algorithmic_bytes_per_update": bytes_per_update, "algorithmic_bytes_per_launch": alg_bytes,
                       "GBps": effective, "note": "SURVEY.md 8d byte model x updates / time: an effective-bandwidth figure "
@@ -443,7 +568,7 @@ def main():
         "best_energy": float(m.energies(best_state[None, :])[0]),
         "mean_energy": float(np.mean(en)),
         "replicas_at_best_energy": int(np.sum(en <= en.min() + 1e-6 * abs(en.min()))),
-        "best_energy_device_f32": float(best[0]),
+        "best_energy_device": float(best[0]), "best_replica_global_id": int(best[1]),
         "host_buffers": {"model_upload_ms": upload_ms, "results_fetch_ms": fetch_ms,
                          "note": "outside the timed region: `value` is measured with the model resident in HBM"},
         "best_cut_edges": cut_edges,
@@ -453,8 +578,9 @@ def main():
         if world == 1:
             out["other_kernels"] = other_kernels(m, Qs, betas, graph, local, args.kernel)
         if not args.no_cpu_baseline and world == 1:
-            perm = prob.perm if prob.perm is not None else np.arange(n)
-            out["cpu_baseline"] = cpu_baseline(m, Qs, betas, (eu, ev), states, en, perm)
+            # the order the device sweeps the caller's variables in (holes of the padded layout take no proposal)
+            perm = prob.perm if prob.perm is not None else (np.argsort(prob._inv) if prob._inv is not None else np.arange(n))
+            out["cpu_baseline"] = cpu_baseline(m, Qs, betas, (eu, ev), eq_states, eq_en, float(np.min(en)), perm)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

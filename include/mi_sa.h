@@ -171,9 +171,19 @@ int mi_sa_anneal_ex(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sw
 int mi_sa_tempering_begin(mi_sa_problem *p, const double *ladder_betas, int T, int chains,
                           uint32_t first_replica, int R_local);
 int mi_sa_tempering_exchange(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *all_energies);
+/* The same exchange with the all-gathered energies ALREADY IN HBM (d_all_energies: a device pointer on this problem's
+ * GPU, T x chains doubles in global order -- the output buffer of the RCCL all-gather): nothing is staged through the
+ * host.  The call returns after the exchange kernel has read the buffer. */
+int mi_sa_tempering_exchange_dev(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *d_all_energies);
 int mi_sa_tempering_state(mi_sa_problem *p, int32_t *out_rung, uint64_t *out_proposed, uint64_t *out_accepted);
 
 int mi_sa_sync(mi_sa_problem *p);
+
+/* DEVICE pointers of the last run's result buffers (states R x n, energies R doubles) after waiting for it; they stay
+ * valid until the next anneal on this handle with MORE replicas, or its destruction.  What a collective library needs
+ * to send results GPU to GPU (the per-round all-gather of parallel tempering, distributed.gather_energies) without a
+ * host copy.  Any of the out pointers may be NULL. */
+int mi_sa_device_results(mi_sa_problem *p, void **out_d_states, double **out_d_energy, int *out_R);
 
 /* Device time of the anneal kernel(s) of the last mi_sa_anneal on this handle, from HIP events
  * recorded on the problem's stream around the launch (milliseconds); implies mi_sa_sync. */
@@ -206,9 +216,9 @@ int mi_sa_best(mi_sa_problem *p, int *out_index, double *out_energy, uint64_t *o
  * problems[d] = the SAME model created on device d (mi_sa_problem_create_*(…, device = d, …)).  The R_total replicas
  * with global ids replica_offset .. are sharded contiguously (remainders to the low devices), every device anneals
  * its shard on its own stream -- concurrently -- and because a replica's random stream is keyed by its GLOBAL id the
- * result does not depend on ndev.  _best: minimum over the devices of the packed (float(E), global id) key -- the
- * reduction the one-process-per-GPU path does with one RCCL MIN all-reduce (distributed.global_best); out_state
- * receives the winner's n states from its owner.  _fetch: states / energies of all replicas in global order, stats
+ * result does not depend on ndev.  _best: the lowest fp64 energy over the devices' own best replicas, ties to the lowest
+ * global id -- the reduction the one-process-per-GPU path does with one RCCL MIN all-reduce
+ * (distributed.global_best_f64); out_state receives the winner's n states from its owner.  _fetch: states / energies of all replicas in global order, stats
  * summed. */
 int mi_multi_gpu_anneal(mi_sa_problem *const *problems, int ndev, int R_total, uint32_t replica_offset,
                         int num_sweeps, const double *betas, uint64_t seed, int resync_interval);

@@ -221,6 +221,7 @@ struct mi_sa_problem {
     int *d_pt_rung = nullptr;
     double *d_pt_betas = nullptr, *d_pt_energy = nullptr;
     float *d_pt_ladder = nullptr;
+    float *d_pt_temps = nullptr;             // per-replica temperatures of the next tempering round (its own buffer: an ordinary anneal on the same handle rewrites d_temps)
     unsigned long long *d_pt_stats = nullptr;
 };
 
@@ -480,6 +481,9 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
             // state in LDS: a half per variable while 16 replicas fit one CU (n <= 4608), else a byte (n <= 9216), else a bit
             // (MI_K2_STATE = bit | byte | half narrows the choice: A/B timing of the three forms on one model)
             const char *force = getenv("MI_K2_STATE");
+#ifdef MI_K2_DEBUG_BUILD
+            const bool debug_linear = getenv("MI_K2_DEBUG_LINEAR") != nullptr;   // (read once, not per adjacency entry)
+#endif
             const bool fits_half = (size_t)slots * 128 * 16 <= 144 * 1024, fits_byte = (size_t)slots * 64 * 16 <= 144 * 1024;
             p->k2_state_bytes = fits_half ? 2 : (fits_byte ? 1 : 0);
             if (force && !strcmp(force, "byte") && fits_byte) p->k2_state_bytes = 1;
@@ -493,11 +497,13 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
                         uint32_t vb;
                         memcpy(&vb, &hv[((size_t)t * D + k) * 64 + lane], 4);
                         const size_t base = (((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3);
-                        if (getenv("MI_K2_DEBUG_LINEAR")) {       // TIMING ONLY (wrong chain): conflict-free gathers
+#ifdef MI_K2_DEBUG_BUILD                                           /* timing-only builds: never in the shipped library */
+                        if (debug_linear) {                       // TIMING ONLY (wrong chain): conflict-free gathers
                             ha[base] = (uint32_t)((lane * 2 + ((k * 128) % (slots * 128))));
                             ha[base + 256] = vb;
                             continue;
                         }
+#endif
                         ha[base] = p->k2_state_bytes == 2 ? 2u * c
                                  : (p->k2_state_bytes == 1 ? c : ((((c >> 5) * 4u) << 8) | (c & 31u)));
                         ha[base + 256] = vb;
@@ -515,8 +521,10 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
                     for (int lane = 0; lane < 64; ++lane)
                         for (int k = 0; k < D; ++k)
                             ha[(((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3)] =
-                                getenv("MI_K2_DEBUG_LINEAR") ? (uint32_t)(lane * 4 + (k * 256) % (slots * 256))   // TIMING ONLY: conflict-free gathers
-                                                             : 4u * hc[((size_t)t * D + k) * 64 + lane];
+#ifdef MI_K2_DEBUG_BUILD
+                                debug_linear ? (uint32_t)(lane * 4 + (k * 256) % (slots * 256)) :   // TIMING ONLY: conflict-free gathers
+#endif
+                                4u * hc[((size_t)t * D + k) * 64 + lane];
                 HIP_TRY(hipMalloc((void **)&p->d_adj4p, ha.size() * sizeof(uint32_t)));
                 HIP_TRY(hipMemcpy(p->d_adj4p, ha.data(), ha.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             }
@@ -605,6 +613,19 @@ static int plan_slot_layout_impl(const int32_t *rowptr, const int32_t *col, int 
         if (rowptr[i + 1] < rowptr[i]) return fail(MI_EINVAL, "rowptr is not monotone at %d", i);
         for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
             if (col[e] < 0 || col[e] >= n) return fail(MI_EINVAL, "bad column %d in row %d", col[e], i);
+    }
+    if (n > (1 << 18)) {
+        // a greedy pass is O(n * slots) and repeats while the layout grows: beyond 262144 variables the packed identity
+        // layout is returned (as mi_sa_plan_slot_order does); clashes = variables with a neighbour in their own slot
+        int clashes = 0;
+        for (int i = 0; i < n; ++i) {
+            pos[i] = i;
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+                if (col[e] / slot == i / slot) { ++clashes; break; }
+        }
+        *out_slots = s0;
+        if (out_clashes) *out_clashes = clashes;
+        return MI_OK;
     }
     // variables by descending degree, ties by index (stable counting sort) -- as mi_sa_plan_slot_order
     int maxdeg = 0;
@@ -746,7 +767,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_xg, p->d_pt_rung, p->d_pt_betas, p->d_pt_energy, p->d_pt_ladder, p->d_pt_stats, p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_xg, p->d_pt_rung, p->d_pt_betas, p->d_pt_energy, p->d_pt_ladder, p->d_pt_temps, p->d_pt_stats, p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -851,10 +872,11 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
     if (!resident || init)
         HIP_TRY(hipStreamSynchronize(p->stream));   // inputs resident before the timed region
     g_kernel.clear();
+    const float *temps_buf = resident ? p->d_pt_temps : p->d_temps;
 
     if (p->kind == MI_KIND_DENSE && p->xl_chunks > 0) {
         DenseXlArgs a;
-        a.Q2 = p->d_Q2xl; a.diag = p->d_diagxl; a.temps = p->d_temps;
+        a.Q2 = p->d_Q2xl; a.diag = p->d_diagxl; a.temps = temps_buf;
         a.init = cont ? (const uint8_t *)p->d_states : (init ? (const uint8_t *)p->d_init : nullptr);
         a.states = (uint8_t *)p->d_states; a.energy = p->d_energy; a.stats = p->d_stats;
         a.offset = p->offset; a.n = p->n; a.R = R; a.num_sweeps = num_sweeps; a.resync = resync_interval;
@@ -915,7 +937,7 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
     } else if (p->kind == MI_KIND_DENSE) {
         DenseArgs a;
-        a.Qp = p->d_Qp; a.Qm = p->d_Qm; a.temps = p->d_temps;
+        a.Qp = p->d_Qp; a.Qm = p->d_Qm; a.temps = temps_buf;
         a.init = cont ? (const uint8_t *)p->d_states : (init ? (const uint8_t *)p->d_init : nullptr);
         a.states = (uint8_t *)p->d_states; a.energy = p->d_energy; a.stats = p->d_stats; a.pace = nullptr;
         a.offset = p->offset; a.n = p->n; a.R = R; a.num_sweeps = num_sweeps; a.resync = resync_interval;
@@ -927,7 +949,7 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
     } else {
         EllArgs a;
-        a.ell_col = p->d_ell_col; a.ell_val = p->d_ell_val; a.lin = p->d_lin; a.temps = p->d_temps;
+        a.ell_col = p->d_ell_col; a.ell_val = p->d_ell_val; a.lin = p->d_lin; a.temps = temps_buf;
         a.init = cont ? p->d_states : (init ? p->d_init : nullptr); a.states = p->d_states; a.energy = p->d_energy; a.stats = p->d_stats;
         a.c_pair = p->c_pair; a.offset = p->offset; a.n = p->n; a.K = p->K; a.R = R; a.num_sweeps = num_sweeps;
         a.resync = resync_interval; a.slots = p->slots; a.D = p->D;
@@ -975,9 +997,9 @@ int mi_sa_tempering_begin(mi_sa_problem *p, const double *ladder_betas, int T, i
     HIP_TRY(hipStreamSynchronize(p->stream));
     int rc = ensure_run_buffers(p, R_local, R_local, false);
     if (rc) return rc;
-    for (void *b : {(void *)p->d_pt_rung, (void *)p->d_pt_betas, (void *)p->d_pt_energy, (void *)p->d_pt_ladder, (void *)p->d_pt_stats})
+    for (void *b : {(void *)p->d_pt_rung, (void *)p->d_pt_betas, (void *)p->d_pt_energy, (void *)p->d_pt_ladder, (void *)p->d_pt_temps, (void *)p->d_pt_stats})
         if (b) (void)hipFree(b);
-    p->d_pt_rung = nullptr; p->d_pt_betas = nullptr; p->d_pt_energy = nullptr; p->d_pt_ladder = nullptr; p->d_pt_stats = nullptr;
+    p->d_pt_rung = nullptr; p->d_pt_betas = nullptr; p->d_pt_energy = nullptr; p->d_pt_ladder = nullptr; p->d_pt_temps = nullptr; p->d_pt_stats = nullptr;
     p->pt_T = 0;
     rc = guarded([&]() -> int {
         std::vector<int> rung((size_t)total);
@@ -990,10 +1012,11 @@ int mi_sa_tempering_begin(mi_sa_problem *p, const double *ladder_betas, int T, i
         HIP_TRY(hipMalloc((void **)&p->d_pt_energy, (size_t)total * sizeof(double)));
         HIP_TRY(hipMalloc((void **)&p->d_pt_ladder, (size_t)T * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&p->d_pt_stats, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&p->d_pt_temps, (size_t)R_local * sizeof(float)));
         HIP_TRY(hipMemcpy(p->d_pt_rung, rung.data(), rung.size() * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_pt_betas, ladder_betas, (size_t)T * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_pt_ladder, lt.data(), lt.size() * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_temps, local.data(), local.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_pt_temps, local.data(), local.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(p->d_pt_stats, 0, 2 * sizeof(unsigned long long)));
         return MI_OK;
     });
@@ -1002,7 +1025,7 @@ int mi_sa_tempering_begin(mi_sa_problem *p, const double *ladder_betas, int T, i
     return MI_OK;
 }
 
-int mi_sa_tempering_exchange(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *all_energies)
+static int tempering_exchange_impl(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *all_energies, bool on_device)
 {
     if (!p) return fail(MI_EINVAL, "NULL problem");
     if (p->pt_T == 0) return fail(MI_ESTATE, "mi_sa_tempering_begin has not been called on this problem");
@@ -1012,15 +1035,40 @@ int mi_sa_tempering_exchange(mi_sa_problem *p, uint32_t round, uint64_t seed, co
         return fail(MI_EINVAL, "this GPU holds %d of the %lld replicas: the exchange needs all energies", p->pt_R_local, total);
     HIP_TRY(hipSetDevice(p->device));
     const double *en = p->d_energy;              // one GPU owns every replica: the energies never leave HBM
-    if (all_energies) {
+    if (all_energies && on_device) {
+        en = all_energies;                       // the all-gather's output buffer, already in HBM
+    } else if (all_energies) {
         HIP_TRY(hipMemcpyAsync(p->d_pt_energy, all_energies, (size_t)total * sizeof(double), hipMemcpyHostToDevice, p->stream));
         en = p->d_pt_energy;
     }
     hipLaunchKernelGGL(k_pt_exchange, dim3(p->pt_chains), dim3(256), (size_t)p->pt_T * sizeof(int), p->stream, en,
-                       p->d_pt_rung, p->d_pt_betas, p->d_pt_ladder, p->d_temps, p->pt_T, p->pt_lo, p->pt_lo + p->pt_R_local,
+                       p->d_pt_rung, p->d_pt_betas, p->d_pt_ladder, p->d_pt_temps, p->pt_T, p->pt_lo, p->pt_lo + p->pt_R_local,
                        round, (uint32_t)seed, (uint32_t)(seed >> 32), p->d_pt_stats);
     HIP_TRY(hipGetLastError());
     if (all_energies) HIP_TRY(hipStreamSynchronize(p->stream));      // the caller's buffer may go away
+    return MI_OK;
+}
+
+int mi_sa_tempering_exchange(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *all_energies)
+{
+    return tempering_exchange_impl(p, round, seed, all_energies, false);
+}
+
+int mi_sa_tempering_exchange_dev(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *d_all_energies)
+{
+    if (!d_all_energies) return fail(MI_EINVAL, "d_all_energies is NULL");
+    return tempering_exchange_impl(p, round, seed, d_all_energies, true);
+}
+
+int mi_sa_device_results(mi_sa_problem *p, void **out_d_states, double **out_d_energy, int *out_R)
+{
+    if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (out_d_states) *out_d_states = p->d_states;
+    if (out_d_energy) *out_d_energy = p->d_energy;
+    if (out_R) *out_R = p->last_R;
     return MI_OK;
 }
 
@@ -1172,14 +1220,18 @@ int mi_multi_gpu_best(mi_sa_problem *const *problems, int ndev, int *out_owner, 
 {
     int rc = multi_check(problems, ndev);
     if (rc) return rc;
+    // one process sees every device's exact fp64 minimum: lowest energy, ties to the lowest global id (the devices
+    // hold ascending id ranges) -- the record a sorted SampleSet of all replicas puts first
     int owner = -1, best_idx = 0;
     uint64_t best_key = ~0ull;
+    double best_e = 0.0;
     for (int d = 0; d < ndev; ++d) {
         int idx = 0;
         uint64_t key = 0;
-        rc = mi_sa_best(problems[d], &idx, nullptr, &key, nullptr);
+        double e = 0.0;
+        rc = mi_sa_best(problems[d], &idx, &e, &key, nullptr);
         if (rc) return rc;
-        if (owner < 0 || key < best_key) { owner = d; best_key = key; best_idx = idx; }
+        if (owner < 0 || e < best_e) { owner = d; best_key = key; best_idx = idx; best_e = e; }
     }
     mi_sa_problem *p = problems[owner];
     HIP_TRY(hipSetDevice(p->device));
@@ -1232,6 +1284,19 @@ int mi_energy_dense_f32_ex(const float *Qs, int n, const uint8_t *X, int R, doub
     if (!Qs || !X || !out_energy) return fail(MI_EINVAL, "NULL argument");
     if (n < 1 || R < 1) return fail(MI_EINVAL, "n and R must be >= 1");
     if (path < 0 || path > 2) return fail(MI_EINVAL, "path must be 0 (auto), 1 (VALU) or 2 (MFMA)");
+    if (path != 1 && (path == 2 || R >= 32)) {
+        // the MFMA kernel multiplies only the blocks on and above the diagonal of a SYMMETRIC Qs: a matrix that is not
+        // (e.g. an upper-triangular QUBO) goes to the exact path when the choice is the library's, and is refused when
+        // the caller asked for the MFMA path by name
+        bool symmetric = true;
+        for (int i = 0; i < n && symmetric; ++i)
+            for (int j = i + 1; j < n; ++j)
+                if (Qs[(size_t)i * n + j] != Qs[(size_t)j * n + i]) { symmetric = false; break; }
+        if (!symmetric) {
+            if (path == 2) return fail(MI_EINVAL, "the MFMA energy path (path = 2) needs a symmetric Qs; use (Q + Q^T) / 2 or path 0 / 1");
+            path = 1;
+        }
+    }
     if (path == 0) path = (R >= 32) ? 2 : 1;      // MFMA only when the batch is a real dense contraction
     int rc = select_device(device);
     if (rc) return rc;

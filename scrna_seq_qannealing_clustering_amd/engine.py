@@ -9,6 +9,9 @@ import numpy as np
 from . import _lib
 
 
+_POTTS_MAX_N = 40000          # mi_sa_problem_create_potts_csr_f32's limit
+
+
 def _ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
 
@@ -77,6 +80,8 @@ class Problem:
             from .models import pad_csr, padded_slot_layout
             seats, nslots, _ = padded_slot_layout(rowptr, col)
             n_caller, n_dev = len(lin), nslots * 64
+            if n_dev > (1 << 20) >= n_caller:        # the holes would push the model over the kernel's size limit
+                return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "slots", energy_model)
             if val64 is not None:
                 val64 = pad_csr(rowptr, col, val64, seats, n_dev)[2]
                 l64 = np.zeros(n_dev, dtype=np.float64)
@@ -125,6 +130,9 @@ class Problem:
             # label 0, in no cluster, never proposed
             from .models import pad_csr, padded_slot_layout
             seats, nslots, _ = padded_slot_layout(rowptr, col)
+            if nslots * 64 > _POTTS_MAX_N >= int(n):  # the holes would push the model over the kernel's size limit (its
+                # LDS budget is checked against the padded size): the packed order, clashing slots on the general path
+                return cls.potts_csr(rowptr, col, val, c_pair, n, num_cases, lin_offset, device, "slots", energy_model)
             n_caller, n = int(n), nslots * 64
             if val64 is not None:
                 val64 = pad_csr(rowptr, col, val64, seats, n)[2]
@@ -252,6 +260,27 @@ class Problem:
             raise ValueError("all_energies must hold the %d energies of the run" % self._pt_total)
         _lib.check(_lib.load().mi_sa_tempering_exchange(self._h, C.c_uint32(int(rnd) & 0xFFFFFFFF),
                                                         C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _ptr(en, C.c_double)))
+
+    def tempering_exchange_device(self, rnd: int, seed: int, all_energies_dev):
+        """The same exchange with the all-gathered energies already in HBM: ``all_energies_dev`` = a contiguous float64
+        torch tensor on this problem's GPU (the output of the RCCL all-gather), read in place."""
+        if all_energies_dev.numel() != self._pt_total or not all_energies_dev.is_contiguous():
+            raise ValueError("all_energies_dev must hold the %d energies of the run, contiguous" % self._pt_total)
+        _lib.check(_lib.load().mi_sa_tempering_exchange_dev(self._h, C.c_uint32(int(rnd) & 0xFFFFFFFF),
+                                                            C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                                                            C.c_void_p(all_energies_dev.data_ptr())))
+
+    def device_energies(self):
+        """The energies of the last run as a float64 torch tensor that ALIASES the library's HBM buffer (no copy;
+        waits for the run; valid until the next anneal on this handle): the send buffer of a GPU-to-GPU collective."""
+        import torch
+        d_en, R = C.c_void_p(), C.c_int(0)
+        _lib.check(_lib.load().mi_sa_device_results(self._h, None, C.byref(d_en), C.byref(R)))
+
+        class _Alias:                     # the array-interface protocol torch.as_tensor understands for device memory
+            __cuda_array_interface__ = {"shape": (int(R.value),), "typestr": "<f8", "data": (int(d_en.value), False),
+                                        "version": 2, "strides": None}
+        return torch.as_tensor(_Alias(), device=torch.device("cuda", self.device))
 
     def tempering_state(self):
         """``(rung of every replica of the run, exchanges proposed, exchanges accepted)``."""

@@ -10,7 +10,7 @@ on even rounds, odd pairs on odd rounds.
 exchange is kernel K6 (`csrc/mi_sa.hip:k_pt_exchange`, C ABI ``mi_sa_tempering_*``): on one GPU the energies,
 the rungs and the per-replica temperatures the next round anneals at never leave HBM -- a round is two kernel
 launches and no copy.  Across GPUs the per-round exchange is ONE all-gather of the R energies
-(``distributed.gather_energies``, RCCL on GPUs / gloo in the CPU tests); every rank then runs the same exchange
+(``distributed.gather_energies``: RCCL from and into HBM on GPUs, gloo through the host in the CPU tests); every rank then runs the same exchange
 kernel on the same energies with the same counter-based stream (seed, round), so no state ever crosses xGMI.
 
 The driver below only sequences rounds; an *engine* supplies ``begin / round / exchange / energies / states /
@@ -49,7 +49,14 @@ class ProblemEngine:
                             sweep_offset=sweep_offset, continue_run=not first, num_sweeps=num_sweeps)
 
     def exchange(self, rnd, seed, all_energies=None):
-        self.problem.tempering_exchange(rnd, seed, all_energies)
+        if all_energies is not None and not isinstance(all_energies, np.ndarray):      # a device tensor (RCCL all-gather)
+            self.problem.tempering_exchange_device(rnd, seed, all_energies)
+        else:
+            self.problem.tempering_exchange(rnd, seed, all_energies)
+
+    def energies_device(self):
+        """This rank's energies as a torch tensor aliasing the library's HBM buffer (the all-gather's send buffer)."""
+        return self.problem.device_energies()
 
     def energies(self) -> np.ndarray:
         return self.problem.fetch(states=False)[1]
@@ -76,11 +83,26 @@ def parallel_tempering(engine, ladder, chains: int, rounds: int, sweeps_per_roun
     lo, hi = D.shard_range(R, rank, world)
     engine.begin(ladder, int(chains), lo, hi)
     hist = []
+    # across GPUs (RCCL): the per-round exchange of energies is ONE all-gather from and into HBM -- the engine hands out
+    # a tensor aliasing its energy buffer, the gathered tensor goes to the exchange kernel as it is; gloo (CPU tests,
+    # rehearsals on one GPU) stages through the host
+    on_device = False
+    if world > 1 and hasattr(engine, "energies_device"):
+        import torch.distributed as dist
+        on_device = dist.get_backend(group) == "nccl"
+
+    def all_energies():
+        if on_device:
+            return D.gather_energies(engine.energies_device(), group=group, num_reads=R)       # (C3) R doubles, in HBM
+        return D.gather_energies(engine.energies(), group=group, num_reads=R)                  # (C3)
+
     for rnd in range(int(rounds)):
         engine.round(int(sweeps_per_round), rnd * int(sweeps_per_round), rnd == 0, initial_states)
         last = rnd + 1 == rounds
         if world > 1:
-            energies = D.gather_energies(engine.energies(), group=group)      # (C3) R doubles
+            if last and not history:
+                break
+            energies = all_energies()
             if history:
                 hist.append(float(energies.min()))
             if not last:
@@ -90,7 +112,12 @@ def parallel_tempering(engine, ladder, chains: int, rounds: int, sweeps_per_roun
                 hist.append(float(engine.energies().min()))
             if not last:
                 engine.exchange(rnd, seed, None)
-    energies = D.gather_energies(engine.energies(), group=group)
+    if int(rounds) < 1:                          # no round ran: the initial rungs, no states
+        return {"energies": np.zeros(0), "rung": np.arange(R, dtype=np.int64) % T, "local_range": (lo, hi),
+                "local_states": None, "best_energy": None, "best_replica": None, "swap_rate": 0.0, "history": hist}
+    energies = all_energies() if world > 1 else engine.energies()
+    if not isinstance(energies, np.ndarray):
+        energies = energies.cpu().numpy()
     rung, proposed, accepted = engine.rungs()
     best = int(np.argmin(energies))
     return {

@@ -52,6 +52,30 @@ def test_owner_follows_from_the_global_id():
             D.owner_of(base + R, R, W, base)
 
 
+def test_fp64_key_orders_like_energy_then_id_and_keeps_what_fp32_loses():
+    rng = np.random.RandomState(1)
+    bits = D.id_bits_for(32768)
+    assert bits == 15 and D.id_bits_for(1) == 1 and D.id_bits_for(2) == 1 and D.id_bits_for(3) == 2
+    es = np.concatenate([rng.normal(scale=1e5, size=300), [0.0, -0.0, 1e-300, -1e-300, -105555.06, -105559.73]])
+    ids = rng.randint(0, 32768, size=len(es))
+    keys = [D.pack_key64(float(e), int(i), bits) for e, i in zip(es, ids)]
+    order = sorted(range(len(es)), key=lambda k: keys[k])
+    got = es[order]
+    assert np.all(np.diff(got) >= -np.abs(got[1:]) * 2.0 ** -(52 - bits) - 1e-290)          # non-decreasing at the key's resolution
+    for e, i, k in zip(es, ids, keys):
+        e2, i2 = D.unpack_key64(k, bits)
+        assert i2 == int(i) and abs(e2 - e) <= abs(e) * 2.0 ** -(52 - bits) + 1e-290
+    # two energies that share an fp32 bucket at |E| ~ 1e5 (resolution 0.0078) are told apart
+    a, b = -105559.7291, -105559.7301
+    assert np.float32(a) == np.float32(b)
+    assert D.pack_key64(b, 9, bits) < D.pack_key64(a, 3, bits)
+    assert D.pack_key64(a, 3, bits) < D.pack_key64(a, 9, bits)                      # exact tie: lower id wins
+    s = [D._to_signed(k) for k in keys]
+    assert sorted(range(len(s)), key=lambda k: s[k]) == order
+    with pytest.raises(ValueError):
+        D.pack_key64(1.0, 1 << bits, bits)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -74,9 +98,16 @@ def _worker(rank, world, port, R, out_dir):
     k = int(np.argmin(en.astype(np.float32)))
     key = D.pack_key(float(en[k]), lo + k)
     e, gid, owner, state = D.global_best(key, st[k], num_reads=R)
-    allen = D.gather_energies(en)
+    k64 = int(np.argmin(en))
+    e64, gid64, owner64, state64 = D.global_best_f64(float(en[k64]), lo + k64, st[k64], num_reads=R)
+    allen = D.gather_energies(en, num_reads=R)                  # ONE collective: the counts follow from shard_range
+    allen2 = D.gather_energies(en)                              # counts gathered first
+    with pytest.raises(ValueError):
+        D.global_best(key, st[k])                               # num_reads missing: raised before any collective is issued
+    with pytest.raises(ValueError):
+        D.global_best_f64(float(en[k64]), R + 5, st[k64], num_reads=R)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), e=e, gid=gid, owner=owner, state=state, allen=allen,
-             lo=lo, hi=hi)
+             allen2=allen2, lo=lo, hi=hi, e64=e64, gid64=gid64, owner64=owner64, state64=state64)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,6 +131,10 @@ def test_two_rank_gloo_global_best_matches_single_process(tmp_path):
         assert int(o["owner"]) == (0 if best < 6 else 1)
         assert np.array_equal(o["state"], st[best])             # winner's labels on every rank
         assert np.array_equal(o["allen"], en)                   # all-gather in global replica order
+        assert np.array_equal(o["allen2"], en)
+        b64 = int(np.argmin(en))                                # fp64 key: the exact minimum, its exact energy
+        assert int(o["gid64"]) == b64 and float(o["e64"]) == float(en[b64])
+        assert int(o["owner64"]) == (0 if b64 < 6 else 1) and np.array_equal(o["state64"], st[b64])
     assert np.array_equal(outs[0]["state"], outs[1]["state"])
 
 
@@ -107,3 +142,28 @@ def test_global_best_without_process_group_is_identity():
     e, gid, owner, state = D.global_best(D.pack_key(-3.25, 17), np.array([1, 0, 1], dtype=np.uint8))
     assert (e, gid, owner) == (-3.25, 17, 0) and state.tolist() == [1, 0, 1]
     assert D.gather_energies(np.array([1.0, 2.0])).tolist() == [1.0, 2.0]
+    e, gid, owner, state = D.global_best_f64(-3.25, 17, np.array([1, 0, 1], dtype=np.uint8), num_reads=32)
+    assert (e, gid, owner) == (-3.25, 17, 0) and state.tolist() == [1, 0, 1]
+
+
+def test_bench_starts_its_own_ranks_as_children_when_typed_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` (what a driver types): N > 1 without WORLD_SIZE in the environment builds the
+    torch.distributed.run command for CHILD processes (the parent has made no GPU call); under a launcher, or with
+    one GPU, the process is a rank itself."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    argv = ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    cmd = bench.rank_launch_command(bench.parse_args(argv), argv, port=29777)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29777"
+    k = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[k + 1:] == argv                                   # the ranks get the arguments as typed
+    assert bench.rank_launch_command(bench.parse_args(["--gpus", "1"]), ["--gpus", "1"]) is None
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert bench.rank_launch_command(bench.parse_args(argv), argv) is None
+    # the launcher relays the children's output and exit code
+    rc = bench.launch_ranks([sys.executable, "-c", "print('{\"ok\": 1}'); raise SystemExit(3)"])
+    assert rc == 3

@@ -200,6 +200,24 @@ def test_energy_kernel_ragged_shapes(n, R):
         assert np.allclose(engine.energy_dense(Qr, Xe, path=2), so.energy_dense_f64(Qr, Xe), rtol=1e-6, atol=1e-6)
 
 
+def test_energy_kernel_asymmetric_matrix_is_not_sent_to_the_symmetric_mfma_path():
+    """The MFMA energy kernel multiplies only the blocks on and above the diagonal (Qs symmetric).  An upper-triangular
+    QUBO matrix at a batch the library would send there (R >= 32) is evaluated on the exact path instead; asking for
+    the MFMA path by name with such a matrix is an error, not a wrong number."""
+    n, R = 300, 40
+    rs = np.random.RandomState(12)
+    U = np.triu(rs.normal(size=(n, n))).astype(np.float32)
+    X = (rs.rand(R, n) < 0.5).astype(np.uint8)
+    Xf = X.astype(np.float64)
+    want = np.einsum("ri,ij,rj->r", Xf, U.astype(np.float64), Xf)
+    assert np.allclose(engine.energy_dense(U, X), want, rtol=1e-12, atol=1e-9)             # auto: exact path
+    assert np.allclose(engine.energy_dense(U, X, path=1), want, rtol=1e-12, atol=1e-9)
+    with pytest.raises(_lib.MiSaError):
+        engine.energy_dense(U, X, path=2)
+    S = ((U + U.T) / 2).astype(np.float32)
+    assert np.allclose(engine.energy_dense(S, X, path=2), np.einsum("ri,ij,rj->r", Xf, S.astype(np.float64), Xf), rtol=1e-6, atol=1e-3)
+
+
 def test_energy_mfma_full_size_batch():
     """BASELINE config 2 shape: 4096 states x n = 2638 on the matrix cores vs the exact VALU form."""
     from scrna_seq_qannealing_clustering_amd import graphs
@@ -494,6 +512,35 @@ def test_full_size_properties_config4_dense_50k():
         sx, ex, ix = p.fetch()
         assert np.array_equal(sg, sx) and ig["accepted"] == ix["accepted"] and ig["accepted"] > 0.99 * 256 * n
         assert np.allclose(eg, ex, rtol=1e-6)
+        # bench.py's own shape (`other_kernels.dense_xl_50k`: one GPU's share of config 4, 1024 replicas): from 1024
+        # replicas up K1g runs its NON-fused chain -- a DIAG and a small pass per block on 8 reserved CUs, beside the
+        # full pass of the previous group on a second CU-masked stream, an event ring between them.  One sweep at the
+        # hot end + one from the middle of the schedule against K1x, and again with both parts in one stream.
+        sched = models.make_beta_schedule(1000, models.default_beta_range(m))
+        two = np.ascontiguousarray(sched[[0, 620]])
+        p.set_option("xl_batched", 0)
+        p.anneal(1024, two, 31)
+        name_k = p.kernel_name()
+        assert "k_xg_diag" in name_k and "k_xg_panel" in name_k and "k_xg_chain" not in name_k, name_k
+        sk, ek, ik = p.fetch()
+        p.set_option("xl_batched", 2)
+        p.anneal(1024, two, 31)
+        assert p.kernel_name().startswith("k_anneal_dense_xl")
+        sy, ey, iy = p.fetch()
+        assert np.array_equal(sk, sy) and ik["accepted"] == iy["accepted"] and ik["accepted"] > 1024 * n
+        assert np.allclose(ek, ey, rtol=1e-6)
+        import os
+        os.environ["MI_XG_ONE_STREAM"] = "1"
+        try:
+            p.set_option("xl_batched", 0)
+            p.anneal(1024, two, 31)
+            s1, e1, i1 = p.fetch()
+        finally:
+            del os.environ["MI_XG_ONE_STREAM"]
+        assert np.array_equal(s1, sy) and i1["accepted"] == iy["accepted"] and np.array_equal(e1, ek)
+    # replicas 63 and 64 of that run (the last of the first range of 64 and the first of the second) against the oracle
+    ost2, oen2, _ = so.sa_dense_philox(Qs, 2, two, 31, replica_offset=63)
+    assert np.array_equal(sk[63:65], ost2) and np.allclose(ek[63:65], oen2, rtol=1e-3)
     ost, oen, ostats = so.sa_dense_philox(Qs, 2, betas, 77, replica_offset=4094)
     del Qs
     assert info["proposals"] == 2 * 2 * n and info["accepted"] == int(ostats[1]) and info["accepted"] > 100

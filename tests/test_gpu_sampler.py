@@ -94,31 +94,56 @@ def test_config1_on_the_gpu():
 def test_equal_reads_against_neal_restatement_on_the_bench_graph():
     """north_star: "equal-or-lower QUBO energy than neal at the same sweep count", on bench.py's workload (n = 2638,
     ONE connected component, so the optimum has to cut edges).  Both samplers run Metropolis sweeps over the same
-    schedule, so at EQUAL reads their energies are draws from the same distribution: asserted as the means of 64 reads
-    agreeing within four standard errors.  At the same sweep count with the reads one GPU runs (4096) the GPU's best
-    is no higher than neal's best of 64; both cut counts are positive integers."""
+    schedule, so at EQUAL reads their energies are draws from the same distribution -- statistically indistinguishable,
+    not "equal": asserted on 256 reads each (bench.equal_reads_stats, the numbers bench.py prints) as the hit rates at
+    the best energy known differing by less than three standard deviations and the means by less than four standard
+    errors.  Which best-of-N is lower in one run is chance and is NOT asserted at equal reads."""
     import bench
     from oracle import sa_oracle as so
     from scrna_seq_qannealing_clustering_amd.engine import Problem
     m, Qs, betas, (eu, ev, w), G = bench.build_workload()
     R = bench.REPLICAS_PER_GPU
     with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                           float(np.float32(m.c_pair)), order="slots", energy_model=(m.val, m.lin, m.c_pair)) as p:
+                           float(np.float32(m.c_pair)), order="padded", energy_model=(m.val, m.lin, m.c_pair)) as p:
         p.anneal(R, betas, bench.SEED)
         st, en, _ = p.fetch()
+        p.anneal(bench.EQUAL_READS, betas, bench.SEED)           # fewer replicas: another kernel, the same chains
+        st_eq, en_eq, _ = p.fetch()
+    assert np.array_equal(st_eq, st[:bench.EQUAL_READS]) and np.array_equal(en_eq, en[:bench.EQUAL_READS])
     h, J, off = so.qubo_to_ising_dense(m.dense_Qs())
-    spins, _, _ = so.sa_ising_neal_dense(h, J, 64, betas, seed=bench.SEED + 1, threads=16)
+    spins, _, _ = so.sa_ising_neal_dense(h, J, bench.EQUAL_READS, betas, seed=bench.SEED + 1, threads=16)
     xn = ((spins + 1) // 2).astype(np.uint8)
     e_neal = m.energies(xn)
-    e_gpu = en[:64]
-    se = np.sqrt(e_neal.var(ddof=1) / 64 + e_gpu.var(ddof=1) / 64)
-    assert abs(e_gpu.mean() - e_neal.mean()) <= 4.0 * se
-    assert en.min() <= e_neal.min() + 1e-6 * abs(e_neal.min())
+    known = min(float(en.min()), float(e_neal.min()))
+    eq = bench.equal_reads_stats(e_neal, en_eq, known)
+    assert abs(eq["hit_rate_difference_sigmas"]) <= 3.0, eq
+    assert abs(eq["mean_difference_standard_errors"]) <= 4.0, eq
+    for side in ("neal", "gpu"):
+        lo, hi = eq[side]["hit_rate_95"]
+        assert lo <= eq[side]["hit_rate"] <= hi
     cut_gpu = int(so.cut_edges(eu, ev, st[int(np.argmin(en))][None, :])[0])
     cut_neal = int(so.cut_edges(eu, ev, xn[int(np.argmin(e_neal))][None, :])[0])
     assert cut_gpu > 0 and cut_neal > 0
     # the best partition is balanced to within a few cells (the gamma (s - n/2)^2 term)
     assert abs(int(st[int(np.argmin(en))].sum()) - m.num_variables // 2) <= 40
+
+
+def test_one_gpu_run_of_4096_reads_is_not_above_the_neal_restatements_best_of_64():
+    """A different statement from the one above, named for what it is: at the same sweep count, with the reads ONE GPU
+    step runs (4096), the best energy is no higher than the best of 64 reads of the neal restatement -- 64 times the
+    draws from the same distribution."""
+    import bench
+    from oracle import sa_oracle as so
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    m, Qs, betas, _, _ = bench.build_workload()
+    with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
+                           float(np.float32(m.c_pair)), order="padded", energy_model=(m.val, m.lin, m.c_pair)) as p:
+        p.anneal(bench.REPLICAS_PER_GPU, betas, bench.SEED)
+        en = p.fetch(states=False)[1]
+    h, J, off = so.qubo_to_ising_dense(m.dense_Qs())
+    spins, _, _ = so.sa_ising_neal_dense(h, J, 64, betas, seed=bench.SEED + 1, threads=16)
+    e_neal = m.energies(((spins + 1) // 2).astype(np.uint8))
+    assert en.min() <= e_neal.min() + 1e-6 * abs(e_neal.min())
 
 
 def test_integration_md_ctypes_example_runs_as_written():
@@ -199,6 +224,6 @@ def test_multi_gpu_c_entries_shard_invariance():
             p.close()
     ost, oen, ostats = so.sa_csr_rank1_philox(*args, 11, betas, 21, replica_offset=5)
     assert np.array_equal(st, ost) and np.allclose(en, oen, rtol=1e-9, atol=1e-9) and int(stats[1]) == int(ostats[1])
-    k = int(np.argmin(oen.astype(np.float32)))                 # the cross-device key compares float(E), ties by id
+    k = int(np.argmin(oen))                                    # the devices' fp64 minima are compared in fp64, ties by id
     assert gid.value == 5 + k and owner.value == (0 if k < 4 else (1 if k < 8 else 2))
     assert e.value == en[k] and np.array_equal(best, st[k])

@@ -95,6 +95,20 @@ def test_padded_slot_layout_keeps_every_edge_between_blocks():
     assert clashes == 0 and nslots >= 70
 
 
+def test_padded_slot_layout_of_a_very_large_graph_is_the_packed_identity():
+    """Beyond 262144 variables the planner does not run its greedy passes (O(n x slots), repeated while the layout
+    grows): seats = indices, as mi_sa_plan_slot_order returns the identity there; clashes are counted, not removed."""
+    import time
+    n = (1 << 18) + 70
+    i = np.arange(n)
+    col = np.stack([(i - 1) % n, (i + 1) % n], axis=1).ravel().astype(np.int32)     # a ring: every variable clashes
+    rowptr = np.arange(0, 2 * n + 1, 2).astype(np.int32)
+    t0 = time.perf_counter()
+    pos, nslots, clashes = models.padded_slot_layout(rowptr, col)
+    assert time.perf_counter() - t0 < 2.0
+    assert np.array_equal(pos, i) and nslots == (n + 63) // 64 and clashes == n
+
+
 def test_order_of_tiny_and_dense_graphs():
     assert models.slot_independent_order(np.array([0, 1, 2]), np.array([1, 0])).tolist() == [0, 1]
     n = 130                                                         # complete graph: conflicts are unavoidable

@@ -98,6 +98,15 @@ def test_oracle_continuation_equals_one_long_run():
     assert np.array_equal(full, b) and np.allclose(efull, eb)
 
 
+def test_zero_rounds_returns_the_initial_ladder_without_touching_results():
+    fx, pm, args = potts_case()
+    eng = OracleEngine("potts", args, 11, lin_offset=pm.lin_offset)
+    out = tempering.parallel_tempering(eng, tempering.geometric_ladder(0.5, 30.0, 4), chains=3, rounds=0,
+                                       sweeps_per_round=5, seed=11)
+    assert out["rung"].tolist() == (np.arange(12) % 4).tolist() and out["local_states"] is None
+    assert out["history"] == [] and out["swap_rate"] == 0.0 and len(out["energies"]) == 0
+
+
 def _pt_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -249,6 +258,46 @@ def test_gpu_exchange_kernel_equals_the_restatement():
             assert np.array_equal(lab, lab2) and np.array_equal(en, en2)
         with pytest.raises(_lib_error()):
             p.tempering_exchange(0, 1, np.zeros(3))
+
+
+@pytest.mark.gpu
+def test_gpu_exchange_from_a_device_buffer_and_ordinary_anneals_in_between():
+    """The multi-GPU round without host staging, on one GPU: the energies as a torch tensor ALIASING the library's HBM
+    buffer (the all-gather's send buffer), the exchange reading a device tensor (the all-gather's output) == the host
+    form == oracle/pt_oracle.py.  And the temperatures of the next round live in a buffer of their own: an ordinary
+    anneal with a long schedule on the same handle in between does not change what the next resident round runs at."""
+    import torch
+    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    fx, pm, args = potts_case("blobs", 3, 0.05)
+    T, chains = 6, 5
+    R = T * chains
+    ladder = np.geomspace(0.3, 9.0, T)
+    with Problem.potts_csr(*args, lin_offset=pm.lin_offset) as p:
+        p.tempering_begin(ladder, chains, 0, R)
+        p.anneal(R, None, 3, num_sweeps=2)
+        en_dev = p.device_energies()
+        lab, en, _ = p.fetch()
+        assert en_dev.dtype == torch.float64 and en_dev.is_cuda and np.array_equal(en_dev.cpu().numpy(), en)
+        p.tempering_exchange_device(0, 77, en_dev.clone())
+        rung, pp, aa = pt_oracle.exchange_step(en, np.arange(R) % T, ladder, T, 0, 77)
+        got, gp, ga = p.tempering_state()
+        assert np.array_equal(got, rung) and (gp, ga) == (pp, aa)
+        with pytest.raises(ValueError):
+            p.tempering_exchange_device(1, 77, en_dev[:3].clone())
+        # reference: the next resident round straight away
+        p.anneal(R, None, 3, num_sweeps=3, sweep_offset=2, continue_run=True)
+        want = p.fetch()
+        # again, with an ordinary 40-sweep anneal on the handle between the exchange and the resident round
+        p.tempering_begin(ladder, chains, 0, R)
+        p.anneal(R, None, 3, num_sweeps=2)
+        p.tempering_exchange(0, 77, en)
+        p.anneal(R, np.geomspace(0.1, 50.0, 40), 123)                       # rewrites the per-sweep temperature buffer
+        p.anneal(R, None, 3, num_sweeps=3, sweep_offset=2, initial_states=lab)
+        have = p.fetch()
+        assert np.array_equal(have[0], want[0]) and np.array_equal(have[1], want[1])
+        ost, _, _ = so.potts_csr_philox(*args, R, ladder[rung], 3, lin_offset=pm.lin_offset, init=lab, sweep_offset=2,
+                                        num_sweeps=3)
+        assert np.array_equal(want[0], ost)
 
 
 def _lib_error():
