@@ -297,7 +297,7 @@ def reads_500(m, graph, rank_device, reads=500, sweeps=1000):
     cluster, n ~ 340).  500 reads are far fewer wavefronts than the chip has SIMDs (1024): the kernel time is one
     wavefront's latency through the sweeps, not throughput."""
     from scrna_seq_qannealing_clustering_amd import graphs, models
-    from scrna_seq_qannealing_clustering_amd.engine import Problem
+    from scrna_seq_qannealing_clustering_amd.engine import Problem, layout_block_for
     out = {"reads": reads, "sweeps": sweeps, "simds": 1024}
     keep = np.flatnonzero(graph.truth == 3)
     new_id = -np.ones(len(graph.truth), dtype=np.int64)
@@ -311,7 +311,8 @@ def reads_500(m, graph, rank_device, reads=500, sweeps=1000):
         b = models.make_beta_schedule(sweeps, models.default_beta_range(mm))
         with Problem.csr_rank1(mm.rowptr, mm.col, mm.val.astype(np.float32), mm.lin.astype(np.float32),
                                float(np.float32(mm.c_pair)), device=rank_device, order="padded",
-                               energy_model=(mm.val, mm.lin, mm.c_pair)) as p:
+                               energy_model=(mm.val, mm.lin, mm.c_pair),
+                               block=layout_block_for(nn, reads, int(np.diff(mm.rowptr).max()))) as p:   # as sampler.py
             p.anneal(reads, b, SEED)                                                   # warm (first launch of this shape)
             p.anneal(reads, b, SEED)
             ms, kname, slots = p.kernel_ms(), p.kernel_name(), p.n_dev // 64

@@ -137,12 +137,36 @@ float orc_neglog_u_carry(uint32_t r)
     return fmaf((float)neg_e, 0x1.62e43p-1f, -(p * t));
 }
 
+/* ... and with the reduction the pair kernel's packed form uses (csrc/mi_sa_device.h neglog_u2): t2 = the exponent
+ * field of (bits(u) + C), in place; m = u times the power of two whose bits are 0x7f000000 - t2; the exponent as
+ * fmaf((float)(int)t2, -2^-23, 127). */
+float orc_neglog_u_scaled(uint32_t r)
+{
+    union { uint32_t u; float f; } cv, sc;
+    cv.u = 0x3f800000u | (r >> 9);
+    cv.f = 2.0f - cv.f;
+    const uint32_t t2 = (cv.u + 0x004afb0cu) & 0x7f800000u;
+    sc.u = 0x7f000000u - t2;
+    const float m = cv.f * sc.f;
+    const float neg_e = fmaf((float)(int)t2, -0x1p-23f, 127.0f);
+    const float t = m - 1.0f;
+    float p = -0x1.9f9af6p-4f;
+    p = fmaf(p, t, 0x1.4cd8dcp-3f);
+    p = fmaf(p, t, -0x1.61491cp-3f);
+    p = fmaf(p, t, 0x1.977bcp-3f);
+    p = fmaf(p, t, -0x1.ff611p-3f);
+    p = fmaf(p, t, 0x1.555a22p-2f);
+    p = fmaf(p, t, -0x1.00007cp-1f);
+    p = fmaf(p, t, 0x1.fffffep-1f);
+    return fmaf(neg_e, 0x1.62e43p-1f, -(p * t));
+}
+
 long orc_neglog_forms_differ(void)
 {
     long bad = 0;
     for (uint32_t k = 0; k < (1u << 23); ++k) {
-        const float a = orc_neglog_u(k << 9), b = orc_neglog_u_carry(k << 9);
-        if (memcmp(&a, &b, sizeof a) != 0) ++bad;
+        const float a = orc_neglog_u(k << 9), b = orc_neglog_u_carry(k << 9), c = orc_neglog_u_scaled(k << 9);
+        if (memcmp(&a, &b, sizeof a) != 0 || memcmp(&a, &c, sizeof a) != 0) ++bad;
     }
     return bad;
 }

@@ -18,6 +18,7 @@ ap.add_argument("--n", type=int, default=2638)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--order", default=None)
+ap.add_argument("--block", type=int, default=64, help="seats per edge-free block of the padded layout (128 / 256: the few-replica kernel)")
 ap.add_argument("--spread", type=float, default=3.0, help="cluster spread of the surrogate graph (3.0 = bench.py workload)")
 ap.add_argument("arms", nargs="*", default=["k2_waves=0"])
 a = ap.parse_args()
@@ -27,7 +28,8 @@ m = models.build_bqm_qubo(G, 0.05, k=8)
 betas = models.make_beta_schedule(a.sweeps, models.default_beta_range(m))
 ref = None
 with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                       float(np.float32(m.c_pair)), order=a.order) as p:
+                       float(np.float32(m.c_pair)), order=a.order, block=a.block) as p:
+    print("n = %d, device slots = %d" % (a.n, p.n_dev // 64))
     for rnd in range(a.rounds):
         for arm in a.arms:
             for kv in arm.split(","):
@@ -39,12 +41,18 @@ with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(n
             ds = p.debug_stats()
             if ds[8:13].any():
                 tot = float(ds[8:13].sum())
-                print("   phase cycles/wave/sweep: pre %.0f loop %.0f wait %.0f field-sum %.0f slot-top %.0f" % tuple(
-                    float(x) / a.replicas / a.sweeps for x in ds[8:13]))
+                if "split" in p.kernel_name():
+                    steps = (p.n_dev // 64) // int(p.kernel_name().split(",")[1].strip(" >"))
+                    print("   K2s cycles/step (wave 0): top+threshold+philox %.0f  gathers+sum %.0f  first solve %.0f  "
+                          "publish+barrier+read %.0f  further passes %.0f" % tuple(
+                              float(x) / a.replicas / a.sweeps / steps for x in ds[8:13]))
+                else:
+                    print("   phase cycles/wave/sweep: pre %.0f loop %.0f wait %.0f field-sum %.0f slot-top %.0f" % tuple(
+                        float(x) / a.replicas / a.sweeps for x in ds[8:13]))
             if a.check:
                 if ref is None:
                     ref = st.copy()
                 assert np.array_equal(ref, st), "arm %s changed the results" % arm
-            print("round %d %-20s %9.2f ms  %.3e upd/s  acc %.3f  minE %.3f" % (
-                rnd, arm, ms, a.replicas * a.sweeps * a.n / ms * 1e3, info["accepted"] / info["proposals"], en.min()),
-                flush=True)
+            print("round %d %-20s %9.2f ms  %.3e upd/s  acc %.3f  minE %.3f  %s" % (
+                rnd, arm, ms, a.replicas * a.sweeps * a.n / ms * 1e3, info["accepted"] / info["proposals"], en.min(),
+                p.kernel_name()), flush=True)

@@ -186,6 +186,7 @@ struct mi_sa_problem {
     uint4 *d_adj4p = nullptr;                // K2p (two replicas per wavefront): the same with neighbour word = 4 * index; null = not eligible
     uint32_t *d_slot_flags = nullptr;        // K2: slots with internal edges
     int k2_state_bytes = 0;                  // K2: byte-per-variable state (16 replicas x n bytes fit one CU's LDS)
+    int k2_free_block = 0;                   // K2s: widest block of seats (256 / 128 / 64; 0 = none) that holds no edge anywhere in the model
     int cus = 0;
     // run buffers
     int cap_R = 0, cap_sweeps = 0;
@@ -210,7 +211,9 @@ struct mi_sa_problem {
     int opt_debug = 0;                       // DenseArgs::debug (diagnostic timing only; results are wrong)
     int opt_min_cluster_size = 0;            // K3: hard lower bound on every cluster's size (CQM_clustering.py:46-48)
     int opt_k2_waves = 0;                    // K2: replicas per workgroup (0 = auto)
-    int opt_k2_pair = 0;                     // K2p: 0 auto (runs of >= 2048 replicas), 1 always when eligible, 2 never
+    int opt_k2_pair = 0;                     // K2p: 0 auto (runs of more replicas than the chip has SIMDs), 1 always when eligible, 2 never
+    int opt_k2_split = 0;                    // K2s (csrc/sparse_split_kernels.hip): 0 auto (few replicas: its one-wavefront form), 1 always when eligible (2 / 4 wavefronts per replica on models laid out in blocks of 128 / 256 seats), 2 never
+    int opt_k2_split_max = 512;              // ... auto: runs of up to this many replicas (fewer wavefronts than half the chip's SIMDs)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
     int last_launches = 1;                   // kernel launches that served the last anneal
@@ -516,6 +519,16 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
             // K2p: every slot free of internal edges, D = 16 / 32, 8 wavefronts x 4 bytes per variable fit a CU's LDS
             bool any_general = false;
             for (int t = 0; t < slots; ++t) any_general = any_general || hf[t] != 0u;
+            // K2s: the widest block of whole slots that holds no edge (a layout planned with slot = 128 / 256 seats)
+            p->k2_free_block = any_general ? 0 : 64;
+            for (int B : {256, 128}) {
+                if (any_general || slots % (B / 64) != 0) continue;
+                bool ok = true;
+                for (int i = 0; i < n && ok; ++i)
+                    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
+                        if (col[e] / B == i / B) { ok = false; break; }
+                if (ok) { p->k2_free_block = B; break; }
+            }
             if (!any_general && (D == 16 || D == 32) && (size_t)slots * 256 * 8 <= 150 * 1024) {
                 for (int t = 0; t < slots; ++t)
                     for (int lane = 0; lane < 64; ++lane)
@@ -826,6 +839,8 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "debug")) { p->opt_debug = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_waves") && ((value >= 0 && value <= 16) || value == 99)) { p->opt_k2_waves = (int)value; return MI_OK; }   // (99: K3 keeps its serial move loop -- A/B timing)
     if (!strcmp(key, "k2_pair") && value >= 0 && value <= 2) { p->opt_k2_pair = (int)value; return MI_OK; }
+    if (!strcmp(key, "k2_split") && value >= 0 && value <= 2) { p->opt_k2_split = (int)value; return MI_OK; }
+    if (!strcmp(key, "k2_split_max") && value >= 0) { p->opt_k2_split_max = (int)value; return MI_OK; }
     if (!strcmp(key, "min_cluster_size") && value >= 0) {
         if (p->kind != MI_KIND_POTTS_CSR) return fail(MI_EINVAL, "min_cluster_size applies to Potts problems");
         p->opt_min_cluster_size = (int)value;
@@ -967,11 +982,26 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
         if (p->kind == MI_KIND_POTTS_CSR) {
             rc = mi_launch_potts(a, p->stream);
-        } else if (p->d_adj4p && p->opt_k2_pair != 2 && (p->opt_k2_pair == 1 || R >= 2048)) {
-            a.adj4 = p->d_adj4p;                      // two replicas per wavefront: half the adjacency traffic per update
-            rc = mi_launch_csr_rank1_pair(a, p->stream);
         } else {
-            rc = mi_launch_csr_rank1(a, p->stream);
+            // which of the kernels of the structured binary model (all run the same chain): an explicit option first;
+            // otherwise few replicas -> K2s in its one-wavefront form (random words a few rounds per step, 32-bit state
+            // cells: 5 % faster than K2 / K2p when every wavefront has a SIMD to itself; its 2 / 4-wavefront forms only on
+            // request: measured break-even), more replicas than the chip has SIMDs -> two replicas per wavefront, else one
+            const bool split_ok = p->k2_free_block >= 64 && p->d_adj4p != nullptr, pair_ok = p->d_adj4p != nullptr;
+            int choice = 0;
+            if (p->opt_k2_split == 1 && split_ok) choice = 2;
+            else if (p->opt_k2_pair == 1 && pair_ok) choice = 1;
+            else if (p->opt_k2_split != 2 && split_ok && p->k2_free_block == 64 && R <= p->opt_k2_split_max) choice = 2;
+            else if (p->opt_k2_pair != 2 && pair_ok && R > 1024) choice = 1;
+            if (choice == 2) {
+                a.adj4 = p->d_adj4p;
+                rc = mi_launch_csr_rank1_split(a, p->k2_free_block / 64, p->stream);
+            } else if (choice == 1) {
+                a.adj4 = p->d_adj4p;                  // two replicas per wavefront: half the adjacency traffic per update
+                rc = mi_launch_csr_rank1_pair(a, p->stream);
+            } else {
+                rc = mi_launch_csr_rank1(a, p->stream);
+            }
         }
         if (rc) return rc;
         HIP_TRY(hipEventRecord(p->ev1, p->stream));

@@ -88,6 +88,38 @@ __device__ __forceinline__ float neglog_u(uint32_t r)
     return __fmaf_rn((float)neg_e, 0x1.62e43p-1f, -lnm);
 }
 
+// neglog_u for TWO random words at once (the two replicas a wavefront of the pair kernel carries): every fp32 step as
+// ONE packed instruction (v_pk_add / v_pk_mul / v_pk_fma_f32 are IEEE per component), the integer steps per word.  The
+// range reduction in the form that packs: with t2 = the exponent field of (bits(u) + C) in place (E << 23),
+//     m = u * 2^(127 - E)          as a multiply by the float whose bits are 0x7f000000 - t2 (exact: a power of two),
+//     (float)(127 - E)             as fma((float)(int)t2, -2^-23, 127) (E * 2^23 converts exactly, the fma is exact),
+// the same m and the same exponent the carry form above produces, so the same bits come out (all 2^23 inputs:
+// oracle/sa_oracle.c orc_neglog_u_scaled, tests/test_oracle_kat.py::test_neglog_reduction_forms_agree).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t neglog_u2(uint32_t ra, uint32_t rb)
+{
+    const f32x2_t mm = {__uint_as_float(__builtin_amdgcn_alignbit(0x7fu, ra, 9)),       // 0x3f800000 | (r >> 9)
+                        __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, rb, 9))};
+    const f32x2_t u = f32x2_t{2.0f, 2.0f} - mm;
+    const uint32_t ta = (__float_as_uint(u.x) + 0x004afb0cu) & 0x7f800000u;
+    const uint32_t tb = (__float_as_uint(u.y) + 0x004afb0cu) & 0x7f800000u;
+    const f32x2_t scale = {__uint_as_float(0x7f000000u - ta), __uint_as_float(0x7f000000u - tb)};
+    const f32x2_t m = u * scale;
+    const f32x2_t ef = {(float)(int)ta, (float)(int)tb};
+    const f32x2_t neg_e = __builtin_elementwise_fma(ef, f32x2_t{-0x1p-23f, -0x1p-23f}, f32x2_t{127.0f, 127.0f});
+    const f32x2_t t = m - f32x2_t{1.0f, 1.0f};
+    f32x2_t p = {-0x1.9f9af6p-4f, -0x1.9f9af6p-4f};
+    p = __builtin_elementwise_fma(p, t, f32x2_t{0x1.4cd8dcp-3f, 0x1.4cd8dcp-3f});
+    p = __builtin_elementwise_fma(p, t, f32x2_t{-0x1.61491cp-3f, -0x1.61491cp-3f});
+    p = __builtin_elementwise_fma(p, t, f32x2_t{0x1.977bcp-3f, 0x1.977bcp-3f});
+    p = __builtin_elementwise_fma(p, t, f32x2_t{-0x1.ff611p-3f, -0x1.ff611p-3f});
+    p = __builtin_elementwise_fma(p, t, f32x2_t{0x1.555a22p-2f, 0x1.555a22p-2f});
+    p = __builtin_elementwise_fma(p, t, f32x2_t{-0x1.00007cp-1f, -0x1.00007cp-1f});
+    p = __builtin_elementwise_fma(p, t, f32x2_t{0x1.fffffep-1f, 0x1.fffffep-1f});
+    const f32x2_t lnm = p * t;
+    return __builtin_elementwise_fma(neg_e, f32x2_t{0x1.62e43p-1f, 0x1.62e43p-1f}, -lnm);
+}
+
 __device__ __forceinline__ float readlane_f(float v, int l)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
@@ -264,6 +296,7 @@ struct EllArgs {
 };
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_csr_rank1_pair(const EllArgs &, hipStream_t);     // sparse_pair_kernels.hip: two replicas per wavefront
+int mi_launch_csr_rank1_split(const EllArgs &, int nw, hipStream_t);   // sparse_split_kernels.hip: nw wavefronts per replica
 int mi_launch_potts(const EllArgs &, hipStream_t);
 
 // K1x (dense_xl_kernels.hip): dense chain for 4096 < n <= 65536, one workgroup per replica

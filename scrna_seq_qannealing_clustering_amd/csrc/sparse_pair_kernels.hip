@@ -71,7 +71,13 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
         const_cast<float *>(a.lin), 0, slots * 256, 0x00020000);
     struct SlotAdj { u32x4 col[G]; u32x4 val[G]; uint32_t lin; };
     const int lane16 = lane * 16;
+#ifdef MI_K2P_NOFETCH
+    // TIMING-ONLY build (`make dbg`, never the shipped library; wrong chain): the adjacency of slot 0 serves every slot, so
+    // the sweep loop issues no vector-memory instruction -- what the kernel would cost without its L2 traffic
+    auto fetch_real = [&](int t) {
+#else
     auto fetch_adj = [&](int t) {
+#endif
         SlotAdj p;
         const int tt = t < slots ? t : slots - 1;
         const int soff = tt * (G * 2048);
@@ -85,30 +91,55 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
         p.lin = __builtin_amdgcn_raw_buffer_load_b32(rs_lin, lane * 4, tt * 256, 0);
         return p;
     };
+#ifdef MI_K2P_NOFETCH
+    const SlotAdj adj0 = fetch_real(0);
+    auto fetch_adj = [&](int) { return adj0; };
+#endif
 
     unsigned long long accepted = 0;
     uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     float TA = 1.0f, TB = 1.0f;
     const float cp = a.c_pair;
 
-    // one slot for both replicas; `wordA` / `wordB` = this slot's random words
+    // one slot for both replicas; `wordA` / `wordB` = this slot's random words.
+    // Order of a slot: (1) the LDS reads are ISSUED -- the lane's own cell and the 16 neighbour cells; (2) while they are in
+    // flight the two thresholds are computed (neglog_u2: the fp32 steps as packed instructions, one for both replicas);
+    // (3) one wait; (4) the field sums; (5) the accept masks.  The reads are inline asm (hipcc adds the zero base of the
+    // dynamic LDS block to every address it computes itself), so the compiler does not count them: every register they
+    // write, and the thresholds, pass THROUGH the wait statement ("+v"), which makes "used only after the wait" a
+    // data dependence, not a scheduling accident -- and the wait is lgkmcnt(0), so whatever LDS or scalar-memory
+    // operation the compiler may place before it is waited for as well (scripts/check_asm_lds.py checks the emitted
+    // code for a read of such a register ahead of its wait at build time).
     auto slot_body = [&](int t, const SlotAdj &cur, uint32_t wordA, uint32_t wordB) {
         const int i = t * 64 + lane;
-        const uint32_t own = cell[i];                               // [x_A | x_B] of this lane's variable
+        uint32_t own;                                               // [x_A | x_B] of this lane's variable
         float gA = __uint_as_float(cur.lin), gB = gA;               // (lanes past n carry lin = +inf: never accepted)
+        float thrA = 0.0f, thrB = 0.0f;
 #pragma unroll
         for (int g0 = 0; g0 < G; g0 += 4) {
             uint32_t word[16];
-            // the packed neighbour word IS the LDS byte address of its cell (one wavefront per workgroup, no static
-            // LDS); asm reads are not counted by the compiler: the wait below names every destination
+            // the packed neighbour word IS the LDS byte address of its cell (one wavefront per workgroup, no static LDS)
+            if (g0 == 0) asm volatile("ds_read_b32 %0, %1" : "=v"(own) : "v"(i * 4));
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"(cur.col[g0 + k / 4][k & 3]));
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(word[4]), "+v"(word[5]),
-                           "+v"(word[6]), "+v"(word[7]), "+v"(word[8]), "+v"(word[9]), "+v"(word[10]), "+v"(word[11]),
-                           "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15])
-                         :: "memory");
+            if (g0 == 0) {
+                asm volatile("" : "+v"(wordA), "+v"(wordB));        // (keeps the threshold arithmetic behind the reads' issue)
+                const f32x2_t thr = neglog_u2(wordA, wordB) * f32x2_t{TA, TB};
+                thrA = thr.x;
+                thrB = thr.y;
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(word[4]), "+v"(word[5]),
+                               "+v"(word[6]), "+v"(word[7]), "+v"(word[8]), "+v"(word[9]), "+v"(word[10]), "+v"(word[11]),
+                               "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15]), "+v"(own), "+v"(thrA), "+v"(thrB)
+                             :: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(word[4]), "+v"(word[5]),
+                               "+v"(word[6]), "+v"(word[7]), "+v"(word[8]), "+v"(word[9]), "+v"(word[10]), "+v"(word[11]),
+                               "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15])
+                             :: "memory");
+            }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const float v = __uint_as_float(cur.val[g0 + k / 4][k & 3]);
@@ -116,15 +147,16 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
                 gB = __builtin_fmaf(v, half_hi(word[k]), gB);
             }
         }
-        const float thrA = neglog_u(wordA) * TA, thrB = neglog_u(wordB) * TB;
         const uint32_t xiA = (own >> 13) & 1u, xiB = own >> 29;     // 0x3c00 -> 1
         const uint64_t XA = __ballot((own & 0xffffu) != 0u), XB = __ballot((own >> 16) != 0u);
         const uint32_t sgA = xiA << 31, sgB = xiB << 31;            // dE = x ? -f : f
-        const float gsA = __uint_as_float(__float_as_uint(gA) ^ sgA), csA = __uint_as_float(__float_as_uint(cp) ^ sgA);
-        const float gsB = __uint_as_float(__float_as_uint(gB) ^ sgB), csB = __uint_as_float(__float_as_uint(cp) ^ sgB);
+        const f32x2_t gs = {__uint_as_float(__float_as_uint(gA) ^ sgA), __uint_as_float(__float_as_uint(gB) ^ sgB)};
+        const f32x2_t cs = {__uint_as_float(__float_as_uint(cp) ^ sgA), __uint_as_float(__float_as_uint(cp) ^ sgB)};
         const int ownA = SA - (int)xiA, ownB = SB - (int)xiB;
-        // accept masks by fixed-point rounds (see k_anneal_csr_rank1): both replicas advance together
-        bool mA = gsA + csA * (float)ownA < thrA, mB = gsB + csB * (float)ownB < thrB;
+        // accept masks by fixed-point rounds (see k_anneal_csr_rank1): both replicas advance together; the oracle's
+        // g + c * (float)(s - x) as one packed multiply and one packed add (no contraction)
+        f32x2_t de = gs + cs * f32x2_t{(float)ownA, (float)ownB};
+        bool mA = de.x < thrA, mB = de.y < thrB;
         uint64_t AA = __ballot(mA), AB = __ballot(mB);
         if ((AA | AB) != 0ull) {                                    // wave-uniform
             const int baseA = ownA - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(XA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)XA, 0u));
@@ -133,8 +165,9 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
                 const uint64_t BA = AA ^ XA, BB = AB ^ XB;
                 const int sA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(BA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)BA, (uint32_t)baseA));
                 const int sB = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(BB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)BB, (uint32_t)baseB));
-                mA = gsA + csA * (float)sA < thrA;
-                mB = gsB + csB * (float)sB < thrB;
+                de = gs + cs * f32x2_t{(float)sA, (float)sB};
+                mA = de.x < thrA;
+                mB = de.y < thrB;
                 const uint64_t NA = __ballot(mA), NB = __ballot(mB);
                 const bool same = NA == AA && NB == AB;
                 AA = NA;

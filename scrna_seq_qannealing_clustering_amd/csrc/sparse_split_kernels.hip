@@ -1,0 +1,370 @@
+// sparse_split_kernels.hip -- K2s: the CSR + uniform-pair anneal for FEW replicas (gfx950 only).
+//
+// Why.  The reference asks for num_reads = 500 (BQM_clustering.py:52) on graphs that shrink under its recursive
+// bisection (:113-203).  500 replicas are 500 (K2) or 250 (K2p) wavefronts on a chip with 1024 SIMDs: every wavefront
+// is alone on its SIMD and the run takes ONE wavefront's latency through slots x sweeps dependent steps of ~970 cycles
+// (19 ms for n = 2638 x 1000 sweeps whether a wavefront carries one replica or two) while three quarters of the chip idle.
+// Here a replica is swept by a WORKGROUP of NW wavefronts: the variables are laid out in BLOCKS of 64 NW mutually
+// non-adjacent seats (mi_sa_plan_slot_layout with slot = 64 NW; holes allowed), wave w owns seats 64 w .. 64 w + 63 of
+// every block, and a sweep is blocks = slots / NW dependent steps instead of slots.
+//
+// Same chain, bit for bit (oracle/sa_oracle.c 2b on the same padded model): inside a block the decisions interact only
+// through s = sum x, so the accept mask of the SEQUENTIAL sweep over the block's 64 NW seats is the fixed point of
+// "evaluate every seat under a guessed mask, rebuild the mask" (k_anneal_csr_rank1) -- here
+// over NW wavefronts: wave w sees s = S + off_w + d_lane, off_w = the net change the waves below it make.  Every wave
+// solves its own 64 seats for a given off_w (rounds inside the wave, no rendezvous), publishes its net change, and after
+// ONE barrier every wave knows all of them; when the offsets the waves used reproduce themselves the block is done
+// (wave k is final after k + 1 passes; in the cold two thirds of a schedule nothing flips and the first pass is the last).
+// The states are written speculatively BEFORE that barrier (and patched if a later pass changes the mask), so the
+// barrier that ends the exchange is also the one that orders this block's writes before the next block's gathers:
+// one barrier per block in the common case.
+//
+// Random words: one Philox block serves four 64-seat slots; every wave computes the blocks of ITS slots (the same words
+// K2 draws: counter (group, lane), sweep, replica), a few rounds per step under the LDS gathers of the running group
+// instead of ten at the head of every fourth slot.  The state is one 32-bit LDS cell per seat (ds_read_b32 gathers cost
+// a lone wavefront two thirds of what ds_read_u16 ones do); NW = 1 is the same step without the exchange: the
+// one-wavefront-per-replica kernel for few replicas on models too small for wider blocks.
+#include "mi_sa_device.h"
+
+namespace mi_sa_impl {
+
+namespace {
+
+typedef _Float16 half_t;
+
+#ifdef MI_K2_PROFILE     /* development build (`make prof`): cycles per phase of a step, wave 0 of every workgroup */
+#define K2S_TICK(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); var += now_ - tick_; tick_ = now_; } while (0)
+#else
+#define K2S_TICK(var) do { } while (0)
+#endif
+
+constexpr int kCommBytes = 8 * 16;               // eight exchange slots of four ints (the waves' net changes)
+
+// One Philox4x32-10 block computed a few rounds per step: the ten rounds of the NEXT group of four slots ride in the
+// shadow of this group's LDS gathers instead of standing, all ten, at the head of every fourth slot.
+struct PhiloxPipe {
+    uint32_t c0, c1, c2, c3;     // counter words after `done` rounds
+    uint32_t k0, k1;             // round keys of the next round
+    int done;
+    __device__ __forceinline__ void start(uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, uint32_t key0, uint32_t key1)
+    {
+        c0 = i0; c1 = i1; c2 = i2; c3 = i3; k0 = key0; k1 = key1; done = 0;
+    }
+    __device__ __forceinline__ void round()
+    {
+        const uint64_t p0 = (uint64_t)PH_M0 * c0, p1 = (uint64_t)PH_M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+        k0 += PH_W0; k1 += PH_W1;
+        ++done;
+    }
+};
+
+template <int D, int NW>
+__global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a)
+{
+    static_assert(NW == 1 || NW == 2 || NW == 4, "one, two or four wavefronts per replica");
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // [0, 4 * 64 * slots): one 32-bit cell per seat, low half = x (0.0 / 1.0)
+    const int lane = threadIdx.x & 63;
+    const int w = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = blockIdx.x;                                       // grid = R workgroups
+    const uint32_t gid = a.replica_offset + (uint32_t)r;
+    const int n = a.n, slots = a.slots, blocks = slots / NW;        // slots is a multiple of NW (launcher)
+    const int comm_at = slots * 256;
+    const uint8_t *init = static_cast<const uint8_t *>(a.init);
+    int *comm = reinterpret_cast<int *>(lds + comm_at);
+    const int gps = (slots + 3) / 4;                                // Philox groups (of four slots) per sweep
+
+    // ---- initial state: wave w fills its own slots; S = sum x over the whole replica ----
+    int S = 0;
+    for (int b = 0; b < blocks; ++b) {
+        const int t = b * NW + w, i = t * 64 + lane;
+        bool x;
+        const bool real = i < n && a.lin[i] < INFINITY;            // (+inf linear term = hole of a padded layout: stays 0)
+        if (init) {
+            x = real && init[(size_t)r * n + i] != 0;
+        } else {
+            uint32_t iw[4];
+            philox4x32_10((uint32_t)((t >> 2) * 64 + lane), 0u, gid, 1u, a.seed_lo, a.seed_hi, iw);
+            const int c = t & 3;
+            x = real && ((c == 0 ? iw[0] : (c == 1 ? iw[1] : (c == 2 ? iw[2] : iw[3]))) >> 31);
+        }
+        reinterpret_cast<uint32_t *>(lds)[i] = x ? 0x3c00u : 0u;
+        S += __popcll(__ballot(x));
+    }
+    if constexpr (NW > 1) {
+        if (lane == 0) comm[w] = S;
+        __syncthreads();
+        S = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) S += __builtin_amdgcn_readfirstlane(comm[k]);
+        __syncthreads();                                            // (comm[0..3] is exchange slot 0: read before reuse)
+    }
+
+    constexpr int G = D / 4;
+    const __amdgpu_buffer_rsrc_t rs_adj = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(a.adj4), 0, slots * G * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.lin), 0, slots * 256, 0x00020000);
+    struct SlotAdj { u32x4 col[G]; u32x4 val[G]; uint32_t lin; };
+    auto fetch_adj = [&](int t) {                                   // the pair kernel's packing: neighbour word = 4 * index
+        SlotAdj p;
+        const int tt = t < slots ? t : slots - 1;
+        const int soff = tt * (G * 2048);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int so = soff + (g / 2) * 4096, io = (g & 1) * 2048;
+            p.col[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16 + io, so, 0);
+            p.val[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16 + io + 1024, so, 0);
+        }
+        p.lin = __builtin_amdgcn_raw_buffer_load_b32(rs_lin, lane * 4, tt * 256, 0);
+        return p;
+    };
+
+#ifdef MI_K2_PROFILE
+    unsigned long long tick_ = __builtin_amdgcn_s_memtime(), t_top = 0, t_sum = 0, t_solve = 0, t_xchg = 0, t_more = 0;
+#endif
+    unsigned long long accepted = 0;
+    uint32_t xc = 0;                                                // exchanges so far (slot xc & 7 of comm)
+    float T = 1.0f;
+    const float cp = a.c_pair;
+    uint32_t sw = a.sweep_offset;
+    int s = 0;
+
+    // random words: `cw` = the four words of the group this wave's current slot belongs to, `nx` = the next group's
+    // block in the making (RPS rounds per step; whatever is missing when the group changes is finished there)
+    constexpr int RPS = NW == 4 ? 10 : (NW == 2 ? 5 : 3);
+    uint32_t cw[4] = {0u, 0u, 0u, 0u};
+    PhiloxPipe nx;
+    int cur_g = -1;                                                 // group of `cw` within the sweep
+    nx.start((uint32_t)((w >> 2) * 64 + lane), sw, gid, 0u, a.seed_lo, a.seed_hi);     // the first slot's group: 0
+
+    // one block: this wave's slot t = b NW + w with its adjacency `cur`
+    auto step = [&](int b, const SlotAdj &cur) {
+        const int t = b * NW + w, i = t * 64 + lane;
+        if ((t >> 2) != cur_g) {                                    // wave-uniform: this slot opens a new group
+            while (nx.done < 10) nx.round();
+            cw[0] = nx.c0; cw[1] = nx.c1; cw[2] = nx.c2; cw[3] = nx.c3;
+            cur_g = t >> 2;
+            // the group this wave needs after it: of the slot NW * (group's remaining steps) ahead, or of the next sweep
+            const int tn = ((t >> 2) + 1) * 4 + (NW == 4 ? w : (NW == 2 ? w : 0));      // first slot of this wave in the next group
+            const bool wrap = tn >= slots;
+            nx.start((uint32_t)((wrap ? 0 : (tn >> 2)) * 64 + lane), wrap ? sw + 1u : sw, gid, 0u, a.seed_lo, a.seed_hi);
+        }
+        // (1) LDS reads, issued together: the lane's own cell, then the 16 neighbour cells (they return in issue order)
+        uint32_t own, word[16];
+        asm volatile("ds_read_b32 %0, %1" : "=v"(own) : "v"(i * 4) : "memory");
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"(cur.col[k / 4][k & 3]));
+        // (2) under the gathers: the threshold of this slot and a share of the next group's random words
+        const int c = t & 3;
+        uint32_t rword = c == 0 ? cw[0] : (c == 1 ? cw[1] : (c == 2 ? cw[2] : cw[3]));
+        asm volatile("" : "+v"(rword));                             // (keeps the arithmetic behind the reads' issue)
+        float thr = neglog_u(rword) * T;
+        // (straight-line: a group lasts at most 4 / NW steps and `nx` restarts with it, so these never pass ten rounds)
+        if constexpr (NW == 1) {
+            nx.round(); nx.round();
+            if (c < 2) nx.round();                                  // 3 + 3 + 2 + 2 over the group's four steps
+        } else {
+#pragma unroll
+            for (int k = 0; k < RPS; ++k) nx.round();
+        }
+        K2S_TICK(t_top);
+        // (3) the field sum, four neighbours at a time as they arrive (counted waits)
+        float gi = __uint_as_float(cur.lin);                        // (lanes past n and holes carry lin = +inf: never accepted)
+#pragma unroll
+        for (int g0 = 0; g0 < G; g0 += 4) {
+            if (g0 > 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"(cur.col[g0 + k / 4][k & 3]));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(own), "+v"(thr) :: "memory");
+                if (q == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(word[4]), "+v"(word[5]), "+v"(word[6]), "+v"(word[7]) :: "memory");
+                if (q == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(word[8]), "+v"(word[9]), "+v"(word[10]), "+v"(word[11]) :: "memory");
+                if (q == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15]) :: "memory");
+#pragma unroll
+                for (int k = 4 * q; k < 4 * q + 4; ++k) {
+                    const half_t hx = __builtin_bit_cast(half_t, (uint16_t)word[k]);
+                    gi = __builtin_fmaf(__uint_as_float(cur.val[g0 + k / 4][k & 3]), (float)hx, gi);   // fma(val, x, g)
+                }
+            }
+        }
+        K2S_TICK(t_sum);
+        // (4) this wave's 64 seats for a given sum at the block's first seat of this wave (k_anneal_csr_rank1's rounds)
+        const uint64_t X = __ballot(own != 0u);
+        const uint32_t xi = own >> 13;                              // 0x3c00 -> 1
+        const uint32_t sgnbit = xi << 31;                           // dE = x ? -f : f
+        const float gs = __uint_as_float(__float_as_uint(gi) ^ sgnbit);
+        const float cs = __uint_as_float(__float_as_uint(cp) ^ sgnbit);
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(X >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)X, 0u));
+        auto solve = [&](int s_in, uint64_t A, bool fresh) -> uint64_t {
+            const int base = s_in - (int)xi - below;
+            if (fresh) {                                            // first guess: nobody below this lane moves
+                A = __ballot(gs + cs * (float)(s_in - (int)xi) < thr);
+                if (A == 0ull) return A;                            // (an empty mask reproduces itself)
+            }
+            for (int round = 0; round < 66; ++round) {
+                const uint64_t Bm = A ^ X;
+                const int s_i = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(Bm >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)Bm, (uint32_t)base));
+                const uint64_t A2 = __ballot(gs + cs * (float)s_i < thr);
+                if (A2 == A) break;
+                A = A2;
+            }
+            return A;
+        };
+        uint64_t A = solve(S, 0ull, true), written = 0ull;
+        K2S_TICK(t_solve);
+        if constexpr (NW == 1) {
+            if (A != 0ull) {                                        // wave-uniform
+                if ((A >> lane) & 1ull) asm volatile("ds_write_b32 %0, %1" :: "v"(i * 4), "v"(own ^ 0x3c00u) : "memory");
+                S += __popcll(A & ~X) - __popcll(A & X);
+                accepted += (unsigned long long)__popcll(A);
+            }
+            (void)written; (void)xc; (void)comm;
+        } else {
+            int used[NW];                                           // the offsets the published changes were computed with
+#pragma unroll
+            for (int k = 0; k < NW; ++k) used[k] = 0;
+            int total = 0;
+            for (int pass = 0; pass < NW + 2; ++pass) {
+                // states as this pass has them (toggle what differs from what is in LDS), then this wave's net change
+                const uint64_t fix = A ^ written;
+                if (fix != 0ull) {                                  // wave-uniform
+                    if ((fix >> lane) & 1ull) {
+                        own ^= 0x3c00u;
+                        asm volatile("ds_write_b32 %0, %1" :: "v"(i * 4), "v"(own) : "memory");
+                    }
+                    written = A;
+                }
+                const int dw = __popcll(A & ~X) - __popcll(A & X);
+                if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(comm_at + (int)(xc & 7u) * 16 + w * 4), "v"(dw) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                u32x4 dv;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dv) : "v"(comm_at + (int)(xc & 7u) * 16) : "memory");
+                ++xc;
+                int d[4];
+                d[0] = __builtin_amdgcn_readfirstlane((int)dv[0]);
+                d[1] = __builtin_amdgcn_readfirstlane((int)dv[1]);
+                d[2] = __builtin_amdgcn_readfirstlane((int)dv[2]);
+                d[3] = __builtin_amdgcn_readfirstlane((int)dv[3]);
+                // offsets these changes imply; done when every wave computed its change with exactly its offset
+                int off[NW], run = 0;
+                bool same = true;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    off[k] = run;
+                    same = same && off[k] == used[k];
+                    run += d[k];
+                }
+                total = run;
+                if (pass == 0) K2S_TICK(t_xchg);
+                if (same) break;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) used[k] = off[k];
+                int my = 0;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) my = k == w ? off[k] : my;
+                A = solve(S + my, A, false);
+            }
+            S += total;
+            accepted += (unsigned long long)__popcll(A);
+        }
+        K2S_TICK(t_more);
+    };
+
+    for (s = 0; s < a.num_sweeps; ++s) {
+        T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[a.temps_per_replica ? r : s])));
+        sw = (uint32_t)s + a.sweep_offset;
+        cur_g = -1;                                                 // (the first slot of a sweep always opens a group)
+        SlotAdj P = fetch_adj(w), Q;
+#pragma unroll 1
+        for (int b = 0; b < blocks; b += 2) {
+            Q = fetch_adj((b + 1) * NW + w);
+            step(b, P);
+            if (b + 1 < blocks) {                                   // wave-uniform
+                P = fetch_adj((b + 2) * NW + w);
+                step(b + 1, Q);
+            }
+        }
+    }
+    __syncthreads();
+#ifdef MI_K2_PROFILE
+    if (threadIdx.x == 0) {
+        atomicAdd(&a.stats[8], t_top); atomicAdd(&a.stats[9], t_sum); atomicAdd(&a.stats[10], t_solve);
+        atomicAdd(&a.stats[11], t_xchg); atomicAdd(&a.stats[12], t_more);
+    }
+#endif
+
+    // ---- epilogue: states out, exact fp64 energy (the sums of k_anneal_csr_rank1, wave w over its own slots) ----
+    uint8_t *dst = static_cast<uint8_t *>(a.states) + (size_t)r * n;
+    const uint32_t *cell = reinterpret_cast<const uint32_t *>(lds);
+    int cnt = 0;
+    double e = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+        const int t = b * NW + w, i = t * 64 + lane;
+        const bool on = cell[i] != 0u;
+        if (i < n) dst[i] = (uint8_t)on;
+        cnt += __popcll(__ballot(on));
+        if (!on) continue;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) {
+            const size_t at = ((size_t)t * D + k) * 64 + lane;
+            const uint32_t cc = a.ell_col[at];
+            const double vv = a.ell_val64 ? a.ell_val64[at] : (double)a.ell_val[at];
+            if (cell[cc] != 0u) acc += vv;
+        }
+        e += (a.lin64 ? a.lin64[i] : (double)a.lin[i]) + 0.5 * acc;
+    }
+    e = wave_sum_f64(e);
+    if constexpr (NW > 1) {
+        __syncthreads();                                            // (every wave is done reading the cells)
+        double *esum = reinterpret_cast<double *>(lds);             // (the state is free now)
+        int *csum = reinterpret_cast<int *>(lds + 64);
+        if (lane == 0) { esum[w] = e; csum[w] = cnt; }
+        __syncthreads();
+        e = 0.0; cnt = 0;
+        for (int k = 0; k < NW; ++k) { e += esum[k]; cnt += csum[k]; }
+    }
+    if (threadIdx.x == 0) {
+        const double cp64 = a.ell_val64 ? a.c_pair64 : (double)a.c_pair;
+        a.energy[r] = e + cp64 * 0.5 * (double)cnt * (double)(cnt - 1) + a.offset;
+    }
+    if (lane == 0) atomicAdd(&a.stats[1], accepted);
+}
+
+template <typename KernelT>
+int launch_split(KernelT kernel, const EllArgs &a, int nw, hipStream_t st)
+{
+    const size_t lds = (size_t)a.slots * 256 + kCommBytes;
+    if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1 split kernel: n = %d exceeds the state LDS budget", a.n);
+    if (a.slots % nw != 0) return fail(MI_EINVAL, "csr_rank1 split kernel: %d slots are not whole blocks of %d", a.slots, nw);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    note_kernel("k_anneal_csr_rank1_split<%d, %d>", a.D, nw);
+    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(64 * nw), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace
+
+// a.adj4 must hold the pair kernel's packing (neighbour word = 4 * index) of a model whose every block of 64 * nw seats
+// is free of internal edges
+int mi_launch_csr_rank1_split(const EllArgs &a, int nw, hipStream_t st)
+{
+    if (!a.adj4) return fail(MI_EHIP, "csr_rank1 split kernel: packed adjacency missing");
+    if (a.D == 16 && nw == 4) return launch_split(k_anneal_csr_rank1_split<16, 4>, a, nw, st);
+    if (a.D == 16 && nw == 2) return launch_split(k_anneal_csr_rank1_split<16, 2>, a, nw, st);
+    if (a.D == 16 && nw == 1) return launch_split(k_anneal_csr_rank1_split<16, 1>, a, nw, st);
+    if (a.D == 32 && nw == 4) return launch_split(k_anneal_csr_rank1_split<32, 4>, a, nw, st);
+    if (a.D == 32 && nw == 2) return launch_split(k_anneal_csr_rank1_split<32, 2>, a, nw, st);
+    if (a.D == 32 && nw == 1) return launch_split(k_anneal_csr_rank1_split<32, 1>, a, nw, st);
+    return fail(MI_EUNSUPPORTED, "csr_rank1 split kernel: width %d / %d wavefronts not built", a.D, nw);
+}
+
+}  // namespace mi_sa_impl

@@ -12,6 +12,16 @@ from . import _lib
 _POTTS_MAX_N = 40000          # mi_sa_problem_create_potts_csr_f32's limit
 
 
+def layout_block_for(n: int, num_reads: int, max_degree: int = 16) -> int:
+    """Seats per edge-free block the sampler lays a structured binary model out in.  64 = one wavefront sweeps a block.
+    128 / 256 lay the model out for the workgroup-per-replica kernel (csrc/sparse_split_kernels.hip: 2 / 4 wavefronts
+    sweep a block together, a sweep is slots / 2 or / 4 dependent steps).  Measured on the MI355X (500 reads x 1000
+    sweeps, n = 2638; profiles/r03_split_kernel.txt) that kernel's steps cost what they save -- the exchange of the
+    wavefronts' net changes takes 600 cycles, and in the hot third of a schedule a block needs two to four of them --
+    so the sampler keeps 64-seat blocks at every size; the wider layouts stay available to callers (``block=``)."""
+    return 64
+
+
 def _ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
 
@@ -51,7 +61,7 @@ class Problem:
 
     @classmethod
     def csr_rank1(cls, rowptr, col, val, lin, c_pair: float, offset: float = 0.0,
-                  device: int = 0, order: Optional[str] = None, energy_model=None) -> "Problem":
+                  device: int = 0, order: Optional[str] = None, energy_model=None, block: int = 64) -> "Problem":
         """``order="slots"`` renumbers the variables on the device so that the 64 variables a wavefront
         sweeps together are (as far as possible) mutually non-adjacent -- the kernel's integer fast path
         (models.slot_independent_order).  States go in and come out in the CALLER's order either way; the
@@ -59,6 +69,11 @@ class Problem:
         ``order="padded"``: the same with holes allowed -- as many blocks of 64 seats as it takes to keep EVERY edge
         between blocks (models.padded_slot_layout); what small or strongly clustered graphs need (the subgraphs of the
         reference's recursive bisection, its 256-node benchmark graphs), where no packed order is edge-free.
+
+        ``block`` (64, 128 or 256; ``order="padded"`` only): seats per edge-free block.  128 / 256 lay the model out for
+        the few-replica kernel (a workgroup of 2 / 4 wavefronts sweeps one replica, a sweep takes slots / 2 or / 4
+        dependent steps: csrc/sparse_split_kernels.hip), which the library then picks for runs of up to 1024 replicas;
+        ``layout_block_for`` is the sampler's choice.
 
         ``energy_model=(val64, lin64, c_pair64)``: the caller's fp64 coefficients (same CSR structure); the
         reported energies are then evaluated on the device in that model (the chain itself runs in fp32)."""
@@ -78,8 +93,12 @@ class Problem:
             # A hole is a variable without couplings whose linear term is +inf: the kernels start it at 0 and
             # never flip it; its fp64 energy coefficients are 0.
             from .models import pad_csr, padded_slot_layout
-            seats, nslots, _ = padded_slot_layout(rowptr, col)
-            n_caller, n_dev = len(lin), nslots * 64
+            if block not in (64, 128, 256):
+                raise ValueError("block must be 64, 128 or 256")
+            seats, nslots, clashes = padded_slot_layout(rowptr, col, slot=block)
+            if block > 64 and clashes:               # no edge-free layout in blocks this wide: the 64-seat layout
+                return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "padded", energy_model)
+            n_caller, n_dev = len(lin), nslots * block
             if n_dev > (1 << 20) >= n_caller:        # the holes would push the model over the kernel's size limit
                 return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "slots", energy_model)
             if val64 is not None:

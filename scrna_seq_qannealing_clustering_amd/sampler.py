@@ -28,7 +28,7 @@ import numpy as np
 
 from . import _lib
 from .bqm import BinaryQuadraticModel, DiscreteQuadraticModel
-from .engine import Problem, energy_dense_f64
+from .engine import Problem, energy_dense_f64, layout_block_for
 from .models import (PottsModel, QuboModel, _csr_from_edges, default_beta_range,
                      make_beta_schedule, qubo_dict_to_model)
 from .sampleset import SampleSet
@@ -231,7 +231,8 @@ class MI355XSampler:
             prob = Problem.csr_rank1(model.rowptr, model.col, model.val.astype(np.float32),
                                      model.lin.astype(np.float32), float(np.float32(model.c_pair)),
                                      offset=model.offset, device=self.device, order="padded",
-                                     energy_model=(model.val, model.lin, model.c_pair))
+                                     energy_model=(model.val, model.lin, model.c_pair),
+                                     block=layout_block_for(n, num_reads, max_deg))
         else:
             dense64 = model.dense_Qs()
             prob = Problem.dense(_symmetric_f32(dense64), offset=model.offset, device=self.device)

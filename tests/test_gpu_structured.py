@@ -215,6 +215,84 @@ def test_csr_rank1_padded_layout_of_a_clustered_subgraph():
     assert np.allclose(ss.record.energy, m.energies(ss.record.sample.astype(np.uint8)), rtol=1e-12)
 
 
+@pytest.mark.parametrize("case", ["cluster_128", "whole_256", "whole_128", "wide_128", "whole_64", "cluster_64", "wide_64"])
+def test_few_replica_kernel_workgroup_per_replica(case):
+    """K2s (csrc/sparse_split_kernels.hip): a workgroup of 1 / 2 / 4 wavefronts sweeps ONE replica over a model laid out
+    in edge-free blocks of 64 / 128 / 256 seats (the one-wavefront form is what runs of up to 512 replicas get by
+    default; the wider ones on request).  Same chain as the oracle on the same padded model: states, accepted counts, fp64 energies, for random and given initial states, a
+    replica offset, a continued run (states + sweep offset), one temperature per replica; and == K2 / K2p on the handle."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    block = int(case.split("_")[1])
+    if case.startswith("cluster"):
+        nodes, eu, ev, w, lab = graphs.synthetic_snn(1500, 5, 15, 15, 6, seed=1)
+        idx = np.flatnonzero(lab == 0)
+        renum = -np.ones(1500, dtype=np.int64)
+        renum[idx] = np.arange(len(idx))
+        sel = np.isin(eu, idx) & np.isin(ev, idx)
+        G = graphs.EdgeListGraph([nodes[i] for i in idx], renum[eu[sel]].astype(np.int32), renum[ev[sel]].astype(np.int32), w[sel])
+    elif case.startswith("wide"):
+        nodes, eu, ev, w, _ = graphs.synthetic_snn(700, 8, 15, 30, 5, seed=3, spread=2.5)       # degree cap 30: the 32-wide layout
+        G = graphs.EdgeListGraph(nodes, eu, ev, w)
+    else:
+        nodes, eu, ev, w, _ = graphs.synthetic_snn(1100, 5, 15, 15, 7, seed=4, spread=3.0)
+        G = graphs.EdgeListGraph(nodes, eu, ev, w)
+    m = models.build_bqm_qubo(G, 0.05)
+    n = m.num_variables
+    c_pair = float(np.float32(m.c_pair))
+    pos, nblocks, clashes = models.padded_slot_layout(m.rowptr, m.col, slot=block)
+    assert clashes == 0
+    N = nblocks * block
+    rp, cc, vv = models.pad_csr(m.rowptr, m.col, f32(m.val), pos, N)
+    lin = np.full(N, np.inf, dtype=np.float32)
+    lin[pos] = f32(m.lin)
+    betas = np.geomspace(2e-3, 40.0, 24)
+    R = 5
+    init = np.random.RandomState(2).randint(0, 2, size=(R, n)).astype(np.uint8)
+    init_dev = np.zeros((R, N), dtype=np.uint8)
+    init_dev[:, pos] = init
+    o_rand = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, R, betas, 8, replica_offset=3)
+    o_init = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, R, betas, 8, init=init_dev)
+    with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), c_pair, order="padded", block=block,
+                           energy_model=(m.val, m.lin, m.c_pair)) as p:
+        assert p.n == n and p.n_dev == N
+        if block > 64:
+            p.set_option("k2_split", 1)
+        p.anneal(R, betas, 8, replica_offset=3)
+        name = p.kernel_name()
+        assert name.startswith("k_anneal_csr_rank1_split<") and name.endswith(", %d>" % (block // 64)), name
+        st, en, info = p.fetch()
+        assert np.array_equal(st, o_rand[0][:, pos]) and info["accepted"] == int(o_rand[2][1])
+        assert info["proposals"] == R * len(betas) * n and np.allclose(en, m.energies(st), rtol=1e-12)
+        i_best, e_best, _, s_best = p.best()
+        assert np.array_equal(s_best, st[i_best]) and e_best == pytest.approx(en.min(), rel=1e-12)
+        p.anneal(R, betas, 8, initial_states=init)
+        st2, en2, info2 = p.fetch()
+        assert np.array_equal(st2, o_init[0][:, pos]) and info2["accepted"] == int(o_init[2][1])
+        # a run continued in two pieces == the run in one; then one constant temperature per replica
+        p.anneal(R, betas[:9], 8, replica_offset=3)
+        p.anneal(R, betas[9:], 8, replica_offset=3, continue_run=True, sweep_offset=9)
+        st3, en3, _ = p.fetch()
+        assert np.array_equal(st3, st) and np.array_equal(en3, en)
+        per = np.geomspace(0.02, 8.0, R)
+        p.anneal(R, per, 9, num_sweeps=7, sweep_offset=100)
+        st4, _, info4 = p.fetch()
+        o_per = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, R, per, 9, sweep_offset=100, num_sweeps=7)
+        assert np.array_equal(st4, o_per[0][:, pos]) and info4["accepted"] == int(o_per[2][1])
+        # the other kernels of the handle run the same chain
+        for key, val, tag in (("k2_split", 2, "k_anneal_csr_rank1<"), ("k2_pair", 1, "pair")):
+            p.set_option("k2_split", 2)
+            p.set_option(key, val)
+            p.anneal(R, betas, 8, replica_offset=3)
+            assert tag in p.kernel_name() and "split" not in p.kernel_name()
+            sx, ex, ix = p.fetch()
+            assert np.array_equal(sx, st) and np.allclose(ex, en, rtol=1e-13) and ix["accepted"] == info["accepted"]
+        # zero sweeps: the initial states come back with their energies
+        p.set_option("k2_split", 1)
+        p.anneal(R, betas[:0], 8, initial_states=init)
+        s0, e0, _ = p.fetch()
+        assert "split" in p.kernel_name() and np.array_equal(s0, init) and np.allclose(e0, m.energies(init), rtol=1e-12)
+
+
 def test_potts_padded_layout_of_a_clustered_subgraph():
     """K3 under order="padded": the holes (mi_sa_problem_set_absent) keep label 0, sit in no cluster -- the size penalty
     does not see them -- and are never proposed.  Equal to the oracle on the same padded model with the same positions
