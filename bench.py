@@ -19,7 +19,7 @@ packed (fp64 energy, replica id) key + a broadcast of the winner's labels (RCCL 
 Rank 0 prints one JSON line.  The model (0.34 MB in CSR form) lives in the L2s, never in HBM traffic terms, so the
 `roofline` object of the CSR kernel is an L2 roofline: `achieved` = bytes the kernel's loads request from L2
 per launch (adjacency + linear terms of every slot of every sweep of every wavefront, counted from the launch
-shape; the TCC_REQ counter of profiles/r02_* agrees) / mean launch time (HIP events), `peak` = 34.5 TB/s
+shape; the TCC_REQ counter of profiles/r03_* agrees) / mean launch time (HIP events), `peak` = 34.5 TB/s
 (MI355X_MICROARCH.md, L2 aggregate), `traffic` = what the fabric counters saw (HBM side).  `effective` keeps
 SURVEY.md 8d's per-update byte model (deg_i*8 + 8) as an effective-bandwidth figure with no fraction.  The one
 shape whose Q really lives in HBM (n = 50 000 dense, 10.6 GB; kernel K1g) is reported under
@@ -202,10 +202,10 @@ def _profile_json(name):
 
 def pmc_traffic(replicas, sweeps, launches, kernel):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload
-    (profiles/r02_pmc_traffic.json, written by scripts/pmc_traffic.py on the GPU box: FETCH_SIZE doubled
+    (profiles/r03_pmc_traffic.json, written by scripts/pmc_traffic.py on the GPU box: FETCH_SIZE doubled
     per the gfx950 note + WRITE_SIZE, averaged over the launches of one step).  None when no profile matches
     this launch shape and kernel."""
-    rec = _profile_json("r02_pmc_traffic.json")
+    rec = _profile_json("r03_pmc_traffic.json")
     if rec and (rec.get("replicas") == replicas and rec.get("sweeps") == sweeps and rec.get("launches") == launches
                 and rec.get("kernel") == kernel):
         return float(rec["hbm_bytes_per_launch"])
@@ -214,9 +214,9 @@ def pmc_traffic(replicas, sweeps, launches, kernel):
 
 def binding_resource(kernel, replicas, sweeps):
     """The counters of the committed SQ / TCC passes over this kernel at this launch shape
-    (profiles/r02_k2_binding.json, scripts/pmc_k2.sh + scripts/k2_binding.py): L2 request bytes, LDS busy, VALU and
+    (profiles/r03_k2_binding.json, scripts/pmc_k2.sh + scripts/k2_binding.py): L2 request bytes, LDS busy, VALU and
     per-wavefront issue.  None when the file was taken on another kernel or shape."""
-    rec = _profile_json("r02_k2_binding.json")
+    rec = _profile_json("r03_k2_binding.json")
     if rec and rec.get("kernel") == kernel and rec.get("replicas") == replicas and rec.get("sweeps") == sweeps:
         return {k: rec[k] for k in rec if k not in ("kernel", "replicas", "sweeps")}
     return None

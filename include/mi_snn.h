@@ -57,6 +57,22 @@ int mi_snn_build_ex_f32(const float *X, int n, int dim, int k, double prune, int
                         int ord2, int device, mi_snn_graph **out);
 int mi_snn_fetch_codes(mi_snn_graph *g, uint8_t *code);
 
+/* The ROUNDING variant of the notebooks (Pbmc3k_normalization_simulated_data.Rmd:597-616): after `- diag(n)`
+ *     snn <- round(snn, digits = 2)                                    (:599, :602)
+ *     snn[snn < 0.16 & snn != 0] <- -0.3      ("also negative edges", :603-605, id_type 3)
+ * and then the same sequential symmetric trim (:611-616) -- which now ranks by the ROUNDED weights (rounding can make
+ * different shared-neighbour counts tie; ties go to the lower row index, R's stable order()).  round_digits = the
+ * `digits` argument (0 .. 6; the weight is rounded in fp64 to the nearest multiple of 10^-digits, halves to even);
+ * negative_below > 0 turns every entry whose rounded weight is below it (and not 0) into a negative edge, 0 keeps all
+ * entries positive.  R's order(decreasing = TRUE) puts a negative entry BELOW the zeros of its column, so the trim of
+ * that column deletes it (with its mirror) whenever the column holds at least `ord` non-negative positions, zeros
+ * included -- always, on a graph of more than a few dozen cells: with ord > 0 the negative entries are therefore
+ * dropped BEFORE the trim and the result holds none (a graph with n - (entries of its densest column) < ord is refused
+ * with MI_EUNSUPPORTED); with ord <= 0 (no trim) they stay and mi_snn_fetch_codes marks them 3.  The caller evaluates
+ * round(shared / (2k - shared), digits) in fp64 and substitutes its negative value (-0.3) on code 3. */
+int mi_snn_build_rounded_f32(const float *X, int n, int dim, int k, double prune, int ord, int round_digits,
+                             double negative_below, int device, mi_snn_graph **out);
+
 /* nnz = stored (directed) entries of the final graph (= 2 x edges when it is symmetric); max_degree over its rows. */
 int mi_snn_info(const mi_snn_graph *g, int *n, int *k, int64_t *nnz, int *max_degree);
 

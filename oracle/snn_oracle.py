@@ -94,3 +94,29 @@ def snn_graph_variant(X, k, prune=0.0, ord=None, symmetric=True, enhance=None, b
     deg = np.bincount(rows[alive], minlength=n)
     out_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
     return nn, out_ptr, col[alive], shared[alive], code[alive]
+
+
+def snn_graph_rounded(X, k, prune=0.0, ord=None, round_digits=2, negative_below=None):
+    """The rounding chunk of Pbmc3k_normalization_simulated_data.Rmd:597-616 on the CSR form: the trim ranks by
+    round(s / (2k - s), digits) (dense ranks; ties by row index as R's stable order()); entries whose rounded weight is
+    below `negative_below` (the notebook's negative edges) sort below the zeros of their column in R, so a trim deletes
+    them -- they leave before it -- provided every column has at least `ord` non-negative positions (asserted); without
+    a trim they stay, code 3.  Returns (nn, rowptr, col, shared, code)."""
+    nn = knn(X, k)
+    rowptr, col, shared = snn_rows(nn, prune)
+    n = len(rowptr) - 1
+    wr = np.round(shared / (2.0 * k - shared), round_digits)
+    neg = (wr < negative_below) & (wr != 0) if negative_below else np.zeros(len(col), dtype=bool)
+    key = np.searchsorted(np.unique(np.round(np.arange(k + 1) / (2.0 * k - np.arange(k + 1)), round_digits)), wr).astype(np.int32)
+    code = np.where(neg, 3, 0).astype(np.uint8)
+    alive = np.ones(len(col), dtype=np.uint8)
+    if ord:
+        if neg.any():
+            assert n - int(np.diff(rowptr).max()) >= ord, "negative entries could survive the trim on a graph this small"
+            alive = (~neg).astype(np.uint8)
+        alive = trim(rowptr, col, key, ord, alive=alive)
+    alive = alive.astype(bool)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    deg = np.bincount(rows[alive], minlength=n)
+    out_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    return nn, out_ptr, col[alive], shared[alive], code[alive]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """<dir>/p*.csv (scripts/pmc_k2.sh: separate rocprofv3 --pmc passes over the headline anneal kernel at the bench
-shape) -> profiles/r02_k2_binding.json: what the kernel uses of each resource that could bind it.
+shape) -> profiles/r03_k2_binding.json: what the kernel uses of each resource that could bind it.
   L2      TCC_REQ x 128 B per request / kernel time, against 34.5 TB/s (MI355X_MICROARCH.md, L2 aggregate)
   LDS     SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles); share of it that is bank-conflict cycles
   VALU    SQ_INSTS_VALU x c / (1024 SIMDs x kernel cycles) for c = 2 (SIMD-32 pass count of a wave64 op) and
@@ -10,7 +10,7 @@ kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs.   usage: k2_binding.py <dir> <replicas
 import csv, glob, json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, replicas, sweeps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-outp = sys.argv[4] if len(sys.argv) > 4 else os.path.join(root, "profiles", "r02_k2_binding.json")
+outp = sys.argv[4] if len(sys.argv) > 4 else os.path.join(root, "profiles", "r03_k2_binding.json")
 vals, kernel, dur = {}, None, []
 for f in sorted(glob.glob(os.path.join(d, "p*.csv"))):
     rows = list(csv.DictReader(open(f)))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ / LDS / cache counters of the headline kernel (K2) on the bench graph: separate rocprofv3 --pmc passes
-# over scripts/perf_k2.py (4096 replicas x <sweeps> sweeps, slot-independent order, bench.py's graph).
+# over scripts/perf_k2.py (4096 replicas x <sweeps> sweeps, the sampler's padded layout, bench.py's graph).
 # usage: scripts/pmc_k2.sh <tag> [sweeps]
 set -u
 tag=${1:-pmc_k2}
@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_IFETCH" "SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_MISC SQ_IFETCH_LEVEL SQ_INST_LEVEL_SMEM SQ_LEVEL_WAVES SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" ; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python $GRAFT_REPO_ROOT/scripts/perf_k2.py --rounds 1 --order slots --sweeps $sweeps > $out/p$i.log 2>&1 || echo "pass $i failed (rc=$?)" >> $out/status.txt
+  timeout -k 10 240 rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python $GRAFT_REPO_ROOT/scripts/perf_k2.py --rounds 1 --order padded --sweeps $sweeps k2_pair=1 > $out/p$i.log 2>&1 || echo "pass $i failed (rc=$?)" >> $out/status.txt
   for f in $(find $out/p$i -name '*counter_collection.csv'); do head -1 $f > $out/p$i.csv; grep anneal_csr $f >> $out/p$i.csv; done
   rm -rf $out/p$i
 done

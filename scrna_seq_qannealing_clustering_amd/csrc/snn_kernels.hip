@@ -432,6 +432,22 @@ __global__ void __launch_bounds__(256) k_make_keys(long long nnz, const int32_t 
         key[e] = table[shared[e] * 3 + (code ? code[e] : 0)];
 }
 
+// the rounding variant (Pbmc3k_normalization_simulated_data.Rmd:597-606): key = rank of round(w, digits) among the values
+// it can take; an entry whose rounded weight the notebook turns into a NEGATIVE edge (table_neg) is dropped when a trim
+// follows (R ranks it below every zero of its column: the trim deletes it, see mi_snn.h) and marked code 3 otherwise
+__global__ void __launch_bounds__(256) k_round_keys(long long nnz, const int32_t *__restrict__ shared,
+                                                    const int32_t *__restrict__ table, int32_t *__restrict__ key,
+                                                    unsigned char *__restrict__ alive, unsigned char *__restrict__ code, int drop_negative)
+{
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < nnz; e += (long long)gridDim.x * 256) {
+        const int32_t t = table[shared[e]];
+        key[e] = t & 0xffff;
+        const bool neg = (t >> 16) != 0;
+        if (neg && drop_negative) alive[e] = 0;
+        code[e] = neg ? (unsigned char)3 : (unsigned char)0;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_compact_count(int n, const int *__restrict__ rowptr,
                                                        const unsigned char *__restrict__ alive, int *__restrict__ deg,
                                                        int *__restrict__ maxdeg)
@@ -510,8 +526,25 @@ int mi_snn_build_f32(const float *X, int n, int dim, int k, double prune, int or
     return mi_snn_build_ex_f32(X, n, dim, k, prune, ord, 0u, 0.0, 0, device, out);
 }
 
+static int snn_build_impl(const float *X, int n, int dim, int k, double prune, int ord, uint32_t flags, double bonus,
+                          int ord2, int round_digits, double negative_below, int device, mi_snn_graph **out);
+
 int mi_snn_build_ex_f32(const float *X, int n, int dim, int k, double prune, int ord, uint32_t flags, double bonus,
                         int ord2, int device, mi_snn_graph **out)
+{
+    return snn_build_impl(X, n, dim, k, prune, ord, flags, bonus, ord2, -1, 0.0, device, out);
+}
+
+int mi_snn_build_rounded_f32(const float *X, int n, int dim, int k, double prune, int ord, int round_digits,
+                             double negative_below, int device, mi_snn_graph **out)
+{
+    if (round_digits < 0 || round_digits > 6) return fail(MI_EINVAL, "round_digits must be 0 .. 6 (got %d)", round_digits);
+    if (!(negative_below >= 0.0)) return fail(MI_EINVAL, "negative_below must be >= 0 (0 = no negative edges)");
+    return snn_build_impl(X, n, dim, k, prune, ord, 0u, 0.0, 0, round_digits, negative_below, device, out);
+}
+
+static int snn_build_impl(const float *X, int n, int dim, int k, double prune, int ord, uint32_t flags, double bonus,
+                          int ord2, int round_digits, double negative_below, int device, mi_snn_graph **out)
 {
     if (!X || !out) return fail(MI_EINVAL, "NULL argument");
     if (flags & ~(uint32_t)(MI_SNN_TRIM_UNSYMMETRIC | MI_SNN_ENHANCE_MUTUAL | MI_SNN_ENHANCE_SUM))
@@ -636,7 +669,49 @@ int mi_snn_build_ex_f32(const float *X, int n, int dim, int k, double prune, int
             HIP_TRY(hipGetLastError());
             return MI_OK;
         };
-        if (ord > 0 && (flags & MI_SNN_TRIM_UNSYMMETRIC)) {
+        if (round_digits >= 0) {
+            // rounded weights (and the notebook's negative edges): the trim ranks by round(s / (2k - s), digits) -- rounding
+            // can make different counts tie, and ties go to the lower row index -- evaluated in fp64 as R holds them
+            const double scale = std::pow(10.0, round_digits);
+            std::vector<double> wr((size_t)k + 1, 0.0);
+            for (int sct = 1; sct <= k; ++sct) wr[(size_t)sct] = std::nearbyint((double)sct / (2.0 * k - (double)sct) * scale) / scale;
+            std::vector<double> uniq(wr);
+            std::sort(uniq.begin(), uniq.end());
+            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            std::vector<int32_t> table((size_t)k + 1);
+            bool any_neg = false;
+            for (int sct = 0; sct <= k; ++sct) {
+                const bool neg = negative_below > 0.0 && wr[(size_t)sct] < negative_below && wr[(size_t)sct] != 0.0;
+                any_neg = any_neg || (neg && sct > 0);
+                table[(size_t)sct] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), wr[(size_t)sct]) - uniq.begin()) | (neg ? 0x10000 : 0);
+            }
+            if (any_neg && ord > 0) {
+                // R sorts a column as [positives, zeros, negatives]: a negative entry survives the trim of its column only
+                // if the column has fewer than ord non-negative ENTRIES, zeros and the diagonal included -- i.e. n - (its
+                // negatives) < ord.  With every column at least ord non-negative positions long all of them are deleted,
+                // which is what dropping them before the trim computes; a graph that small is refused.
+                std::vector<int> hdeg((size_t)n);
+                HIP_TRY(hipMemcpyAsync(hdeg.data(), d_deg, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                int maxdeg0 = 0;
+                for (int i = 0; i < n; ++i) maxdeg0 = std::max(maxdeg0, hdeg[(size_t)i]);
+                if (n - maxdeg0 < ord)
+                    return fail(MI_EUNSUPPORTED, "negative edges on a graph this small (n = %d, densest column %d entries, ord = %d) "
+                                "could survive the trim; not supported", n, maxdeg0, ord);
+            }
+            HIP_TRY(hipMalloc((void **)&d_table, table.size() * sizeof(int32_t)));
+            HIP_TRY(hipMalloc((void **)&d_key, (size_t)(nnz0 > 0 ? nnz0 : 1) * sizeof(int32_t)));
+            HIP_TRY(hipMalloc((void **)&d_code0, (size_t)(nnz0 > 0 ? nnz0 : 1)));
+            HIP_TRY(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_round_keys, dim3(1024), dim3(256), 0, st, (long long)nnz0, d_sh0, d_table, d_key, d_alive, d_code0,
+                               ord > 0 ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));                   // (table goes out of scope)
+            if (ord > 0) {
+                const int r3 = trim_symmetric(d_key, ord);
+                if (r3) return r3;
+            }
+        } else if (ord > 0 && (flags & MI_SNN_TRIM_UNSYMMETRIC)) {
             hipLaunchKernelGGL(k_trim_cols, dim3((n + 3) / 4), dim3(256), 0, st, n, ord, (const int *)d_ptr0, d_col0, d_sh0, d_alive);
             HIP_TRY(hipGetLastError());
         } else if (ord > 0) {

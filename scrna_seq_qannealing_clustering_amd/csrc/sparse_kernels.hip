@@ -499,9 +499,15 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                 if constexpr (D != 0) {
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
+                        // compare + select written out: hipcc narrows the label compare to a byte / word SDWA form, and
+                        // every SDWA compare that writes vcc is followed by an s_nop before the select may read it
+                        // (34 of them per slot); the plain 32-bit pair needs none
                         const int lj = lab[cur.col[k]];
-                        ha = ha + ((lj == la) ? cur.val[k] : 0.0f);
-                        hb = hb + ((lj == lb) ? cur.val[k] : 0.0f);
+                        float ta, tb;
+                        asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(ta) : "v"(lj), "v"(la), "v"(cur.val[k]) : "vcc");
+                        asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(tb) : "v"(lj), "v"(lb), "v"(cur.val[k]) : "vcc");
+                        ha = ha + ta;
+                        hb = hb + tb;
                     }
                 } else {
                     for (int k0 = 0; k0 < W; k0 += 16) {     // padding entries: (the variable itself, +0.0f)

@@ -63,7 +63,9 @@ def _knn_exact(X: np.ndarray, k: int, block: int = 2048) -> np.ndarray:
 
 
 def snn_from_points(X: np.ndarray, k: int, ord: Optional[int], symmetric: bool = True,
-                    enhance: Optional[str] = None, bonus: float = 2.0, ord2: Optional[int] = None) -> np.ndarray:
+                    enhance: Optional[str] = None, bonus: float = 2.0, ord2: Optional[int] = None,
+                    round_digits: Optional[int] = None, negative_below: Optional[float] = None,
+                    negative_value: float = -0.3) -> np.ndarray:
     """Dense SNN weight matrix (zero diagonal), trimmed to degree <= ``ord`` if given.
 
     A LITERAL dense numpy restatement of the R lines (O(n^2) memory, Python loop over columns): it generates
@@ -72,7 +74,9 @@ def snn_from_points(X: np.ndarray, k: int, ord: Optional[int], symmetric: bool =
     the HIP library is missing.  The optional arguments are the notebooks' optional chunks
     (`Pbmc3k_general_data_preparation.Rmd:77-123`): ``symmetric=False`` the UNSYMMETRIC first trim (:77-83),
     ``enhance="mutual"`` Method 2 (:85-101, ``+ bonus * mutual``), ``enhance="sum"`` ``A + t(A)`` (:103-113),
-    ``ord2`` the second trim (:116-123)."""
+    ``ord2`` the second trim (:116-123); ``round_digits`` / ``negative_below`` / ``negative_value`` the rounding chunk
+    of `Pbmc3k_normalization_simulated_data.Rmd:597-606` (``round(snn, digits=2)``; ``snn[snn < 0.16 & snn != 0] <-
+    -0.3``) ahead of the trim."""
     n = X.shape[0]
     nn = _knn_exact(X, k)
     M = np.zeros((n, n), dtype=np.float32)
@@ -80,6 +84,10 @@ def snn_from_points(X: np.ndarray, k: int, ord: Optional[int], symmetric: bool =
     shared = (M @ M.T).astype(np.int64)                        # |N(i) & N(j)|
     snn = np.where(shared > 0, shared / (2.0 * k - shared), 0.0)
     np.fill_diagonal(snn, 0.0)                                 # snn - diag(n)  (Rmd :72)
+    if round_digits is not None:                               # Pbmc3k_normalization_simulated_data.Rmd:599 / :602
+        snn = np.round(snn, round_digits)
+        if negative_below is not None:                         # :603-605
+            snn[(snn < negative_below) & (snn != 0)] = negative_value
 
     def trim_symmetric(cap):
         # Rmd :75-79 -- for i in 1..n: to_delete = order(snn[,i], decreasing=TRUE)[(ord+1):n];

@@ -19,13 +19,16 @@ from . import _lib
 class SnnGraph:
     """Result of :func:`build_snn`: CSR of shared-neighbour counts plus the kNN table."""
 
-    def __init__(self, n, k, nn, rowptr, col, shared, timing, code=None, bonus=2.0, symmetric=True):
+    def __init__(self, n, k, nn, rowptr, col, shared, timing, code=None, bonus=2.0, symmetric=True,
+                 round_digits=None, negative_value=-0.3):
         self.n, self.k = int(n), int(k)
         self.nn, self.rowptr, self.col, self.shared = nn, rowptr, col, shared
         self.timing = timing
         self.code = code if code is not None else np.zeros(len(col), dtype=np.uint8)
         self.bonus = float(bonus)
         self.symmetric = bool(symmetric)     # False: the stored rows are the COLUMNS of an asymmetric matrix
+        self.round_digits = round_digits     # the rounding variant: weights are round(w, digits); code 3 = a negative edge
+        self.negative_value = float(negative_value)
 
     @property
     def weights(self) -> np.ndarray:
@@ -33,6 +36,9 @@ class SnnGraph:
         enhancement applied where the build asked for one (``w + bonus`` on mutual entries, ``w + w`` on doubled ones)."""
         s = self.shared.astype(np.float64)
         w = s / (2.0 * self.k - s)
+        if self.round_digits is not None:                      # Pbmc3k_normalization_simulated_data.Rmd:599-605
+            w = np.round(w, self.round_digits)
+            return np.where(self.code == 3, self.negative_value, w)
         return np.where(self.code == 1, w + self.bonus, np.where(self.code == 2, w + w, w))
 
     @property
@@ -74,14 +80,21 @@ class SnnGraph:
 
 def build_snn(X: np.ndarray, k: int, prune: float = 0.0, ord: Optional[int] = None, device: int = 0,
               symmetric: bool = True, enhance: Optional[str] = None, mutual_bonus: float = 2.0,
-              ord2: Optional[int] = None) -> SnnGraph:
+              ord2: Optional[int] = None, round_digits: Optional[int] = None, negative_below: Optional[float] = None,
+              negative_value: float = -0.3) -> SnnGraph:
     """``X``: (n, dim) coordinates (fp32 on the device), ``k`` = Seurat's ``k.param`` (self included),
     ``prune`` = ``prune.SNN``, ``ord`` = degree cap of the trim loop (None: no trim).
 
     The notebooks' optional chunks (`Pbmc3k_general_data_preparation.Rmd:77-123`, `Kidney_data.Rmd:235-266` -- the
     reference's ``..._trimmed_15enh.gexf`` inputs, `main.py:105-110`): ``symmetric=False`` = the UNSYMMETRIC first
     trim (columns only), ``enhance="mutual"`` adds ``mutual_bonus`` (2 in the PBMC notebook, 1 in the kidney one) to
-    entries present in both directions, ``enhance="sum"`` forms ``A + t(A)``, ``ord2`` trims a second time."""
+    entries present in both directions, ``enhance="sum"`` forms ``A + t(A)``, ``ord2`` trims a second time.
+
+    The rounding variant (`Pbmc3k_normalization_simulated_data.Rmd:597-616`): ``round_digits=2`` rounds the weights
+    (``round(snn, digits=2)``) before the trim, which then ranks by the rounded values; ``negative_below=0.16`` with
+    ``negative_value=-0.3`` is the notebook's "also negative edges" branch (``snn[snn < 0.16 & snn != 0] <- -0.3``):
+    R's ``order(decreasing=TRUE)`` ranks those entries below the zeros, so a trim deletes them all (include/mi_snn.h);
+    without a trim they stay in the graph with the negative weight."""
     X = np.ascontiguousarray(X, dtype=np.float32)
     if X.ndim != 2:
         raise ValueError("X must be (n, dim)")
@@ -91,9 +104,18 @@ def build_snn(X: np.ndarray, k: int, prune: float = 0.0, ord: Optional[int] = No
     if enhance not in (None, "mutual", "sum"):
         raise ValueError("enhance must be None, 'mutual' or 'sum'")
     flags = (0 if symmetric else 1) | (2 if enhance == "mutual" else 0) | (4 if enhance == "sum" else 0)
-    _lib.check(lib.mi_snn_build_ex_f32(X.ctypes.data_as(C.POINTER(C.c_float)), n, dim, int(k), float(prune),
-                                       int(ord or 0), C.c_uint32(flags), float(mutual_bonus), int(ord2 or 0),
-                                       int(device), C.byref(h)))
+    if round_digits is None and negative_below is not None:
+        raise ValueError("negative_below applies to the rounded weights: give round_digits")
+    if round_digits is not None:
+        if flags or ord2:
+            raise ValueError("the rounding variant is the notebook's plain pipeline: symmetric trim, no enhancement")
+        _lib.check(lib.mi_snn_build_rounded_f32(X.ctypes.data_as(C.POINTER(C.c_float)), n, dim, int(k), float(prune),
+                                                int(ord or 0), int(round_digits), float(negative_below or 0.0),
+                                                int(device), C.byref(h)))
+    else:
+        _lib.check(lib.mi_snn_build_ex_f32(X.ctypes.data_as(C.POINTER(C.c_float)), n, dim, int(k), float(prune),
+                                           int(ord or 0), C.c_uint32(flags), float(mutual_bonus), int(ord2 or 0),
+                                           int(device), C.byref(h)))
     try:
         nnz = C.c_int64(0)
         _lib.check(lib.mi_snn_info(h, None, None, C.byref(nnz), None))
@@ -112,4 +134,4 @@ def build_snn(X: np.ndarray, k: int, prune: float = 0.0, ord: Optional[int] = No
         lib.mi_snn_destroy(h)
     return SnnGraph(n, k, nn, rowptr, col, shared,
                     {"knn_ms": t[0].value, "snn_ms": t[1].value, "trim_ms": t[2].value}, code=code, bonus=mutual_bonus,
-                    symmetric=bool(symmetric) or enhance == "sum")
+                    symmetric=bool(symmetric) or enhance == "sum", round_digits=round_digits, negative_value=negative_value)

@@ -81,6 +81,34 @@ def test_duplicate_points_and_size_independent_properties():
     assert np.array_equal(g.nn[:, 0], np.arange(n))
 
 
+@pytest.mark.parametrize("n,k,ord_,dim,digits,neg", [(3000, 5, 8, 15, 2, None), (3000, 5, 8, 15, 2, 0.16), (1200, 30, 12, 10, 2, 0.05),
+                                                    (900, 5, None, 8, 2, 0.16), (700, 64, 20, 6, 2, None)])
+def test_rounding_and_negative_edge_variant_equals_the_oracle(n, k, ord_, dim, digits, neg):
+    """snn.build_snn(round_digits=, negative_below=): the rounding chunk of Pbmc3k_normalization_simulated_data.Rmd:597-616
+    (the notebook's own parameters first: k = 5, ord = 8, two digits, negative edges below 0.16) against the oracle, which
+    the literal dense restatement of the R lines pins (tests/test_snn_oracle.py): graph, counts, codes, fp64 weights."""
+    X = cloud(n, dim, seed=7 * n + k, clusters=5)
+    g = snn.build_snn(X, k, 0.0, ord_, round_digits=digits, negative_below=neg)
+    nn, rowptr, col, shared, code = sn.snn_graph_rounded(X, k, 0.0, ord_, digits, neg)
+    assert np.array_equal(g.nn, nn) and np.array_equal(g.rowptr, rowptr)
+    assert np.array_equal(g.col, col) and np.array_equal(g.shared, shared) and np.array_equal(g.code, code)
+    want = np.where(code == 3, -0.3, np.round(shared / (2.0 * k - shared), digits))
+    assert np.array_equal(g.weights, want)
+    if ord_ is not None:
+        assert g.max_degree <= ord_ and (g.weights > 0).all()
+    elif neg:
+        assert (g.weights == -0.3).any()
+    nodes, eu, ev, w = g.edge_list()
+    assert len(w) * 2 == len(g.col)
+
+
+def test_negative_edges_on_a_tiny_dense_graph_are_refused():
+    with pytest.raises(_lib.MiSaError):
+        snn.build_snn(cloud(12, 2, seed=3, clusters=1), 6, 0.0, 10, round_digits=2, negative_below=0.5)
+    with pytest.raises(ValueError):
+        snn.build_snn(cloud(100, 3, seed=0), 5, 0.0, 8, negative_below=0.16)            # needs round_digits
+
+
 def test_built_graph_feeds_the_clustering_model():
     g = snn.build_snn(cloud(600, 10, seed=5, clusters=3), 5, 0.0, 15)
     m = models.build_bqm_qubo(g.to_graph(), 0.05)

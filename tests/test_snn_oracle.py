@@ -86,3 +86,36 @@ def test_edge_list_of_an_asymmetric_matrix_is_what_networkx_builds():
     want = [(u, v, d["weight"]) for u, v, d in G.edges(data=True)]
     eu, ev, w = graphs.edges_from_matrix(A)
     assert [(int(a), int(b), float(c)) for a, b, c in zip(eu, ev, w)] == want
+
+
+@pytest.mark.parametrize("n,k,ord_,dim,digits,neg", [(300, 5, 8, 15, 2, None), (300, 5, 8, 15, 2, 0.16), (500, 10, 8, 20, 2, 0.16),
+                                                    (400, 30, 12, 10, 2, 0.05), (350, 5, None, 8, 2, 0.16), (257, 8, 6, 4, 1, 0.25)])
+def test_rounding_and_negative_edge_chunk_equals_its_dense_restatement(n, k, ord_, dim, digits, neg):
+    """Pbmc3k_normalization_simulated_data.Rmd:597-616: round(snn, 2), optionally snn[snn < 0.16 & snn != 0] <- -0.3, then
+    the trim -- ranked by the ROUNDED values (k = 30, one digit ... : different counts tie), the negative entries below
+    every zero of their column, so the trim deletes them.  Oracle (CSR) == the literal dense restatement, bit for bit."""
+    X = cloud(n, dim, seed=5 * n + k)
+    nn, rowptr, col, shared, code = sn.snn_graph_rounded(X, k, 0.0, ord_, digits, neg)
+    dense = graphs.snn_from_points(X.astype(np.float64), k, ord_, round_digits=digits, negative_below=neg, negative_value=-0.3)
+    W = np.zeros((n, n))
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    W[rows, col] = np.where(code == 3, -0.3, np.round(shared / (2.0 * k - shared), digits))
+    assert np.array_equal(W, dense) and np.array_equal(W, W.T)
+    if ord_ is not None:
+        assert np.diff(rowptr).max() <= ord_ and not (code == 3).any()     # the trim removed every negative edge
+    elif neg:
+        assert (code == 3).any() and (dense < 0).any()
+    if neg and ord_ is not None and k <= 10:                   # (at k = 30 the light edges never reach a top-12 anyway)
+        # not the positive-only graph with the light edges merely rounded: the support differs
+        plain = graphs.snn_from_points(X.astype(np.float64), k, ord_, round_digits=digits)
+        assert not np.array_equal(plain != 0, dense != 0)
+
+
+def test_negative_edges_can_survive_the_trim_of_a_tiny_dense_graph():
+    """Why the build refuses negative edges on a graph with n - (densest column) < ord: R keeps the first `ord` positions
+    of [positives, zeros, negatives], and with too few non-negative positions some negatives are among them."""
+    X = cloud(12, 2, seed=3, clusters=1)
+    dense = graphs.snn_from_points(X.astype(np.float64), 6, 10, round_digits=2, negative_below=0.5, negative_value=-0.3)
+    assert (dense < 0).any()
+    with pytest.raises(AssertionError):
+        sn.snn_graph_rounded(X, 6, 0.0, 10, 2, 0.5)
