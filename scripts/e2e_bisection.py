@@ -31,6 +31,15 @@ def traced(model, **kw):
 s.sample_qubo = traced
 clustering_bqm(G.subgraph(list(G.nodes)[:300]), 0, None, "mi355x", 0.05, 0, "once", 5, 3, 0, sampler=s)   # warm
 calls.clear()
+# (1) the plain wall time, no profiler attached; (2) the same run under cProfile for the split
+for rep in range(3):
+    t0 = time.perf_counter()
+    clustering_bqm(G, 0, None, "mi355x", 0.05, 0, "iter_limit", 5, 3, 0, sampler=s,
+                   sampler_kwargs={"seed": 7} if "--seed" in sys.argv else None)
+    wall_plain = time.perf_counter() - t0
+    print("recursive bisection, 4 levels, no profiler, run %d: %.3f s wall, %d sampler calls, kernels %.1f ms" % (
+        rep, wall_plain, len(calls), sum(c[2]["kernel_ms"] for c in calls)))
+    calls.clear()
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()

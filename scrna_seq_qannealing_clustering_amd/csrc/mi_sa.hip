@@ -522,7 +522,7 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
             // K2s: the widest block of whole slots that holds no edge (a layout planned with slot = 128 / 256 seats)
             p->k2_free_block = any_general ? 0 : 64;
             for (int B : {256, 128}) {
-                if (any_general || slots % (B / 64) != 0) continue;
+                if (any_general || slots % 4 != 0) continue;         // (whole groups of four slots: one Philox block each)
                 bool ok = true;
                 for (int i = 0; i < n && ok; ++i)
                     for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)

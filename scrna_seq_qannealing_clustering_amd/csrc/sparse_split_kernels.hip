@@ -34,11 +34,14 @@ typedef _Float16 half_t;
 
 #ifdef MI_K2_PROFILE     /* development build (`make prof`): cycles per phase of a step, wave 0 of every workgroup */
 #define K2S_TICK(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); var += now_ - tick_; tick_ = now_; } while (0)
+#define K2S_TICK0(var) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); var += now_ - tick_; tick_ = now_; } while (0)   /* (no wait: LDS reads stay in flight) */
 #else
 #define K2S_TICK(var) do { } while (0)
+#define K2S_TICK0(var) do { } while (0)
 #endif
 
 constexpr int kCommBytes = 8 * 16;               // eight exchange slots of four ints (the waves' net changes)
+constexpr int kRingBytes = 4 * 64 * 16;          // NW > 1: four groups of random words in flight, [4][64 lanes][4 words]
 
 // One Philox4x32-10 block computed a few rounds per step: the ten rounds of the NEXT group of four slots ride in the
 // shadow of this group's LDS gathers instead of standing, all ten, at the head of every fourth slot.
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
     const int r = blockIdx.x;                                       // grid = R workgroups
     const uint32_t gid = a.replica_offset + (uint32_t)r;
     const int n = a.n, slots = a.slots, blocks = slots / NW;        // slots is a multiple of NW (launcher)
-    const int comm_at = slots * 256;
+    const int comm_at = slots * 256, ring_at = comm_at + kCommBytes;
     const uint8_t *init = static_cast<const uint8_t *>(a.init);
     int *comm = reinterpret_cast<int *>(lds + comm_at);
     const int gps = (slots + 3) / 4;                                // Philox groups (of four slots) per sweep
@@ -122,7 +125,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
     };
 
 #ifdef MI_K2_PROFILE
-    unsigned long long tick_ = __builtin_amdgcn_s_memtime(), t_top = 0, t_sum = 0, t_solve = 0, t_xchg = 0, t_more = 0;
+    unsigned long long tick_ = __builtin_amdgcn_s_memtime(), t_top = 0, t_sum = 0, t_solve = 0, t_xchg = 0, t_more = 0, t_issue = 0, t_arith = 0;
 #endif
     unsigned long long accepted = 0;
     uint32_t xc = 0;                                                // exchanges so far (slot xc & 7 of comm)
@@ -131,45 +134,94 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
     uint32_t sw = a.sweep_offset;
     int s = 0;
 
-    // random words: `cw` = the four words of the group this wave's current slot belongs to, `nx` = the next group's
-    // block in the making (RPS rounds per step; whatever is missing when the group changes is finished there)
-    constexpr int RPS = NW == 4 ? 10 : (NW == 2 ? 5 : 3);
+    // Random words.  One Philox block serves four slots (one group).
+    //   NW = 1: `cw` = the words of the group the wave is in, `nx` = the next group's block in the making, 3 + 3 + 2 + 2
+    //   rounds over the group's four steps (whatever is missing when the group changes -- a short last group -- is
+    //   finished there).
+    //   NW > 1: the groups of the run, numbered q = sweep * groups_per_sweep + g in the order they are used, are computed
+    //   by the waves in turn (q % NW), each wave spreading the ten rounds of its next group over the four steps before
+    //   the one that needs it (slots is a multiple of four: a group per 4 / NW steps, every wave one group per four
+    //   steps), and shared through a ring of four LDS entries: written during the step BEFORE the group's first one (the
+    //   barrier that ends every step publishes it), read as one word per lane at the top of a step.
     uint32_t cw[4] = {0u, 0u, 0u, 0u};
     PhiloxPipe nx;
-    int cur_g = -1;                                                 // group of `cw` within the sweep
-    nx.start((uint32_t)((w >> 2) * 64 + lane), sw, gid, 0u, a.seed_lo, a.seed_hi);     // the first slot's group: 0
+    int cur_g = -1;                                                 // NW = 1: group of `cw` within the sweep
+    int next_q = w;                                                 // NW > 1: the group this wave produces next
+    auto start_group = [&](int q) {                                 // counter of group q of the run
+        const int qs = q / gps, qg = q - qs * gps;
+        nx.start((uint32_t)(qg * 64 + lane), a.sweep_offset + (uint32_t)qs, gid, 0u, a.seed_lo, a.seed_hi);
+    };
+    auto publish_group = [&](int q) {
+        const u32x4 v = {nx.c0, nx.c1, nx.c2, nx.c3};
+        asm volatile("ds_write_b128 %0, %1" :: "v"(ring_at + (q & 3) * 1024 + lane * 16), "v"(v) : "memory");
+    };
+    (void)cw; (void)cur_g; (void)next_q;
+    if constexpr (NW == 1) {
+        nx.start((uint32_t)lane, sw, gid, 0u, a.seed_lo, a.seed_hi);       // the first slot's group: 0
+    } else {
+        start_group(next_q);                                        // this wave's first group, whole, before the first step
+#pragma unroll
+        for (int k = 0; k < 10; ++k) nx.round();
+        publish_group(next_q);
+        next_q += NW;
+        start_group(next_q);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    int ustep = 0;                                                  // steps done so far (all sweeps)
 
     // one block: this wave's slot t = b NW + w with its adjacency `cur`
     auto step = [&](int b, const SlotAdj &cur) {
         const int t = b * NW + w, i = t * 64 + lane;
-        if ((t >> 2) != cur_g) {                                    // wave-uniform: this slot opens a new group
-            while (nx.done < 10) nx.round();
-            cw[0] = nx.c0; cw[1] = nx.c1; cw[2] = nx.c2; cw[3] = nx.c3;
-            cur_g = t >> 2;
-            // the group this wave needs after it: of the slot NW * (group's remaining steps) ahead, or of the next sweep
-            const int tn = ((t >> 2) + 1) * 4 + (NW == 4 ? w : (NW == 2 ? w : 0));      // first slot of this wave in the next group
-            const bool wrap = tn >= slots;
-            nx.start((uint32_t)((wrap ? 0 : (tn >> 2)) * 64 + lane), wrap ? sw + 1u : sw, gid, 0u, a.seed_lo, a.seed_hi);
+        const int c = t & 3;
+        if constexpr (NW == 1) {
+            if ((t >> 2) != cur_g) {                                // wave-uniform: this slot opens a new group
+                while (nx.done < 10) nx.round();
+                cw[0] = nx.c0; cw[1] = nx.c1; cw[2] = nx.c2; cw[3] = nx.c3;
+                cur_g = t >> 2;
+                const int tn = ((t >> 2) + 1) * 4;                  // first slot of the next group, or of the next sweep
+                const bool wrap = tn >= slots;
+                nx.start((uint32_t)((wrap ? 0 : (tn >> 2)) * 64 + lane), wrap ? sw + 1u : sw, gid, 0u, a.seed_lo, a.seed_hi);
+            }
         }
-        // (1) LDS reads, issued together: the lane's own cell, then the 16 neighbour cells (they return in issue order)
-        uint32_t own, word[16];
+        // (1) LDS reads, issued together: (NW > 1: this slot's random word,) the lane's own cell, then the 16 neighbour
+        // cells; they return in issue order
+        uint32_t own, word[16], rword = 0u;
+        if constexpr (NW > 1)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(rword) : "v"(ring_at + ((s * gps + (t >> 2)) & 3) * 1024 + lane * 16 + c * 4) : "memory");
         asm volatile("ds_read_b32 %0, %1" : "=v"(own) : "v"(i * 4) : "memory");
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"(cur.col[k / 4][k & 3]));
+        K2S_TICK0(t_issue);
         // (2) under the gathers: the threshold of this slot and a share of the next group's random words
-        const int c = t & 3;
-        uint32_t rword = c == 0 ? cw[0] : (c == 1 ? cw[1] : (c == 2 ? cw[2] : cw[3]));
-        asm volatile("" : "+v"(rword));                             // (keeps the arithmetic behind the reads' issue)
-        float thr = neglog_u(rword) * T;
-        // (straight-line: a group lasts at most 4 / NW steps and `nx` restarts with it, so these never pass ten rounds)
+        // (the empty asm statements keep this arithmetic BEHIND the reads' issue: hipcc would hoist it above them)
+        float thr;
         if constexpr (NW == 1) {
+            rword = c == 0 ? cw[0] : (c == 1 ? cw[1] : (c == 2 ? cw[2] : cw[3]));
+            asm volatile("" : "+v"(rword), "+v"(nx.c0), "+v"(nx.c1), "+v"(nx.c2), "+v"(nx.c3));
             nx.round(); nx.round();
             if (c < 2) nx.round();                                  // 3 + 3 + 2 + 2 over the group's four steps
+            thr = neglog_u(rword) * T;
         } else {
-#pragma unroll
-            for (int k = 0; k < RPS; ++k) nx.round();
+            // this wave's share of the random words: its next group over the four steps that end one step before the
+            // group's first (group q opens step q * 4 / NW: a group every 4 / NW steps, NW producers)
+            asm volatile("" : "+v"(nx.c0), "+v"(nx.c1), "+v"(nx.c2), "+v"(nx.c3));
+            const int due = next_q * (4 / NW) - 1;                  // the step during which group next_q must be published
+            const int left = due - ustep;                           // 3, 2, 1, 0 inside the group's four steps
+            if (left <= 3) {                                        // wave-uniform
+                nx.round(); nx.round();
+                if (left >= 2) nx.round();                          // 3 + 3 + 2 + 2
+                if (left == 0) {
+                    publish_group(next_q);
+                    next_q += NW;
+                    start_group(next_q);
+                }
+            }
+            // the random word was issued first: at most the 15 youngest reads may still be in flight behind it
+            asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(rword) :: "memory");
+            thr = neglog_u(rword) * T;
         }
+        K2S_TICK0(t_arith);
         K2S_TICK(t_top);
         // (3) the field sum, four neighbours at a time as they arrive (counted waits)
         float gi = __uint_as_float(cur.lin);                        // (lanes past n and holes carry lin = +inf: never accepted)
@@ -274,6 +326,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
             S += total;
             accepted += (unsigned long long)__popcll(A);
         }
+        ++ustep;
         K2S_TICK(t_more);
     };
 
@@ -296,7 +349,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
 #ifdef MI_K2_PROFILE
     if (threadIdx.x == 0) {
         atomicAdd(&a.stats[8], t_top); atomicAdd(&a.stats[9], t_sum); atomicAdd(&a.stats[10], t_solve);
-        atomicAdd(&a.stats[11], t_xchg); atomicAdd(&a.stats[12], t_more);
+        atomicAdd(&a.stats[11], t_xchg); atomicAdd(&a.stats[12], t_more); atomicAdd(&a.stats[13], t_issue); atomicAdd(&a.stats[6], t_arith);
     }
 #endif
 
@@ -340,9 +393,11 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
 template <typename KernelT>
 int launch_split(KernelT kernel, const EllArgs &a, int nw, hipStream_t st)
 {
-    const size_t lds = (size_t)a.slots * 256 + kCommBytes;
+    const size_t lds = (size_t)a.slots * 256 + kCommBytes + (nw > 1 ? kRingBytes : 0);
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1 split kernel: n = %d exceeds the state LDS budget", a.n);
     if (a.slots % nw != 0) return fail(MI_EINVAL, "csr_rank1 split kernel: %d slots are not whole blocks of %d", a.slots, nw);
+    if (nw > 1 && a.slots % 4 != 0)
+        return fail(MI_EINVAL, "csr_rank1 split kernel: with %d wavefronts per replica the slots (%d) must come in whole groups of four", nw, a.slots);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     note_kernel("k_anneal_csr_rank1_split<%d, %d>", a.D, nw);

@@ -16,9 +16,11 @@ def layout_block_for(n: int, num_reads: int, max_degree: int = 16) -> int:
     """Seats per edge-free block the sampler lays a structured binary model out in.  64 = one wavefront sweeps a block.
     128 / 256 lay the model out for the workgroup-per-replica kernel (csrc/sparse_split_kernels.hip: 2 / 4 wavefronts
     sweep a block together, a sweep is slots / 2 or / 4 dependent steps).  Measured on the MI355X (500 reads x 1000
-    sweeps, n = 2638; profiles/r03_split_kernel.txt) that kernel's steps cost what they save -- the exchange of the
-    wavefronts' net changes takes 600 cycles, and in the hot third of a schedule a block needs two to four of them --
-    so the sampler keeps 64-seat blocks at every size; the wider layouts stay available to callers (``block=``)."""
+    sweeps, n = 2638; profiles/r03_split_kernel.txt): 16.4 ms with four wavefronts per replica against 17.7 ms with
+    one -- a step of four slots costs 2200 cycles where four steps of one cost 3900, but the wavefronts of a CU then
+    issue their LDS gathers in bursts (850 cycles until the last is accepted), the exchange of their net changes takes
+    650, and in the hot third of a schedule a block needs two to four of them.  8 %: the sampler keeps 64-seat blocks
+    at every size; the wider layouts stay available to callers (``block=`` + option ``k2_split`` = 1)."""
     return 64
 
 
@@ -98,6 +100,8 @@ class Problem:
             seats, nslots, clashes = padded_slot_layout(rowptr, col, slot=block)
             if block > 64 and clashes:               # no edge-free layout in blocks this wide: the 64-seat layout
                 return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "padded", energy_model)
+            if block == 128 and nslots % 2:          # (the two-wavefront kernel takes whole groups of four 64-seat slots)
+                nslots += 1
             n_caller, n_dev = len(lin), nslots * block
             if n_dev > (1 << 20) >= n_caller:        # the holes would push the model over the kernel's size limit
                 return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "slots", energy_model)

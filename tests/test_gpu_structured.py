@@ -241,6 +241,8 @@ def test_few_replica_kernel_workgroup_per_replica(case):
     c_pair = float(np.float32(m.c_pair))
     pos, nblocks, clashes = models.padded_slot_layout(m.rowptr, m.col, slot=block)
     assert clashes == 0
+    if block == 128 and nblocks % 2:
+        nblocks += 1                                   # (whole groups of four 64-seat slots: one more block of holes)
     N = nblocks * block
     rp, cc, vv = models.pad_csr(m.rowptr, m.col, f32(m.val), pos, N)
     lin = np.full(N, np.inf, dtype=np.float32)

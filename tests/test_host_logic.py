@@ -148,3 +148,42 @@ def test_pack_expression_bit_layout():
         for g in (0, 1, 63, 64, 65, 127, 128, 130):
             assert ((int(bits[i, g // 64]) >> (g % 64)) & 1) == int(X[i, g] != 0)
     assert int(bits[0, 2]) >> 3 == 0                                # padding bits are clear
+
+
+def test_the_isa_guard_for_inline_asm_lds_reads_sees_a_premature_use(tmp_path):
+    """scripts/check_asm_lds.py (run by __graft_entry__.build()): a register written by an asm ds_read is pending until a
+    lgkmcnt wait retires it -- in issue order, so lgkmcnt(1) retires all but the youngest -- and naming it before is flagged."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("check_asm_lds", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "scripts", "check_asm_lds.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    good = """_Zkernel_a:
+\t;;#ASMSTART
+\tds_read_b32 v10, v3
+\t;;#ASMEND
+\t;;#ASMSTART
+\tds_read_b32 v11, v4
+\t;;#ASMEND
+\tv_add_u32_e32 v5, v6, v7
+\t;;#ASMSTART
+\ts_waitcnt lgkmcnt(1)
+\t;;#ASMEND
+\tv_add_f32_e32 v12, v10, v12
+\ts_waitcnt lgkmcnt(0)
+\tv_add_f32_e32 v12, v11, v12
+\ts_endpgm
+"""
+    p = tmp_path / "good.s"
+    p.write_text(good)
+    assert mod.check_asm(str(p)) == (1, 2, [])
+    bad = good.replace("v_add_f32_e32 v12, v10, v12", "v_add_f32_e32 v12, v11, v12")      # v11 is still in flight there
+    q = tmp_path / "bad.s"
+    q.write_text(bad)
+    kernels, reads, viol = mod.check_asm(str(q))
+    assert (kernels, reads) == (1, 2) and len(viol) == 1 and viol[0][3][0][0] == 11
+    ranged = good.replace("v_add_u32_e32 v5, v6, v7", "v_pk_mul_f32 v[20:21], v[10:11], v[22:23]")   # a register pair names it too
+    r = tmp_path / "ranged.s"
+    r.write_text(ranged)
+    assert len(mod.check_asm(str(r))[2]) == 1
