@@ -167,3 +167,47 @@ def test_bench_starts_its_own_ranks_as_children_when_typed_without_a_launcher(mo
     # the launcher relays the children's output and exit code
     rc = bench.launch_ranks([sys.executable, "-c", "print('{\"ok\": 1}'); raise SystemExit(3)"])
     assert rc == 3
+
+
+def _rccl_worker(out_path):
+    """One rank, backend "nccl" (= RCCL) on cuda:0: the three collectives of the path on device tensors."""
+    import json
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    dev = torch.device("cuda", 0)
+    key = D.pack_key64(-105559.7291, 26, D.id_bits_for(4096))
+    k = torch.tensor([D._to_signed(key)], dtype=torch.int64, device=dev)
+    dist.all_reduce(k, op=dist.ReduceOp.MIN)                                     # (C1)
+    st = torch.arange(300, dtype=torch.uint8, device=dev)
+    dist.broadcast(st, src=0)                                                    # (C2)
+    en = torch.linspace(-3.0, 5.0, 128, dtype=torch.float64, device=dev)
+    out = torch.empty(128, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, en)                                         # (C3)
+    torch.cuda.synchronize()
+    res = {"key_ok": D._from_signed(int(k.item())) == key, "bcast_ok": bool((st.cpu() == torch.arange(300, dtype=torch.uint8)).all()),
+           "gather_ok": bool(torch.equal(out, en)), "backend": dist.get_backend()}
+    dist.barrier()
+    dist.destroy_process_group()
+    json.dump(res, open(out_path, "w"))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_rccl_executes_the_paths_collectives_on_this_gpu(tmp_path):
+    """RCCL itself (torch.distributed backend "nccl"), one rank on the box's one GPU, in a child process with
+    HSA_ENABLE_IPC_MODE_LEGACY=0 in place before its first HIP call: the 8-byte MIN all-reduce of the packed key, the
+    broadcast of n label bytes and the all-gather of energies into a device tensor run and return what they were given.
+    (Several ranks need several GPUs: the driver's scaling run.)"""
+    import json
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl.json")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(out,))
+    p.start()
+    p.join(240)
+    assert p.exitcode == 0
+    res = json.load(open(out))
+    assert res == {"key_ok": True, "bcast_ok": True, "gather_ok": True, "backend": "nccl"}

@@ -295,3 +295,16 @@ def test_root_graph_arrays_give_every_subgraph_view_without_a_python_walk():
     unweighted = nx.path_graph(5)
     assert models.RootGraphArrays.of(unweighted) is None              # no weights: the plain walk decides (it raises)
     assert models.RootGraphArrays.of(nx.DiGraph()) is None
+
+
+def test_qubo_dict_with_exotic_labels_keeps_them():
+    """Labels are arbitrary hashables: None, tuples, ints and strings side by side come back as given, in
+    order of first appearance, whichever of the two lifting paths handles the dict."""
+    Q = {(None, None): 1.0, (None, 3): 2.0, (3, "a"): -1.0, (("t", 1), "a"): 0.5, (("t", 1), ("t", 1)): 0.25}
+    m = models.qubo_dict_to_model(Q)
+    assert m.variables == [None, 3, "a", ("t", 1)]
+    assert m.lin.tolist() == [1.0, 0.0, 0.0, 0.25]
+    x = np.array([[1, 1, 0, 1], [0, 1, 1, 1]], dtype=np.uint8)
+    assert np.allclose(m.energies(x), [1.0 + 2.0 + 0.25, -1.0 + 0.5 + 0.25])
+    Q2 = {("b", "b"): 1.0, ("a", "b"): 2.0, ("a", "a"): -3.0}
+    assert models.qubo_dict_to_model(Q2).variables == ["b", "a"]
