@@ -152,7 +152,8 @@ def slot_independent_order(rowptr, col, slot=64):
 def padded_slot_layout(rowptr, col, slot=64, max_slots=None):
     """Restatement of mi_sa_plan_slot_layout: the greedy pass of ``slot_independent_order`` with ``nslots`` blocks of
     ``slot`` seats each (no short last block), repeated with nslots = ceil(n / slot), then + max(1, nslots // 8) per
-    try, until no variable shares a block with a neighbour; beyond ``max_slots`` the packed result stands.  Returns
+    try, until no variable shares a block with a neighbour; beyond ``max_slots`` the packed result stands; when holes were
+    needed a DSATUR colouring is tried too and kept if it needs fewer blocks (graphs up to 4096 variables).  Returns
     (pos, nslots, clashes): pos[i] = block * slot + rank of i inside its block (by original index)."""
     import numpy as np
     rowptr = np.asarray(rowptr)
@@ -194,6 +195,37 @@ def padded_slot_layout(rowptr, col, slot=64, max_slots=None):
             nslots = s0
             break
         nslots = nxt
+    if clashes == 0 and nslots > s0 and n <= 4096:
+        # small graphs: a saturation-degree colouring (DSATUR; ties by degree, then index; lowest colour with a free seat),
+        # kept when it needs fewer blocks than the greedy layout
+        C = nslots
+        deg = np.diff(rowptr)
+        seen = np.zeros((n, C), dtype=bool)
+        sat = np.zeros(n, dtype=np.int64)
+        colour = np.full(n, -1, dtype=np.int64)
+        fill2 = np.zeros(C, dtype=np.int64)
+        used, ok = 0, True
+        for _ in range(n):
+            cand = np.flatnonzero(colour < 0)
+            key = sat[cand] * (int(deg.max()) + 1) + deg[cand]
+            v = int(cand[np.argmax(key)])                       # (argmax returns the first maximum: lowest index)
+            free = np.flatnonzero(~seen[v] & (fill2 < slot))
+            if len(free) == 0:
+                ok = False
+                break
+            c = int(free[0])
+            colour[v] = c
+            fill2[c] += 1
+            used = max(used, c + 1)
+            if used >= C:
+                ok = False
+                break
+            nb = col[rowptr[v]:rowptr[v + 1]]
+            fresh = nb[~seen[nb, c]]
+            seen[fresh, c] = True
+            np.add.at(sat, fresh, 1)
+        if ok and s0 <= used < nslots:
+            where, nslots = colour, used
     pos = np.empty(n, dtype=np.int64)
     seat = np.zeros(nslots, dtype=np.int64)
     for i in range(n):

@@ -659,6 +659,42 @@ static int plan_slot_layout_impl(const int32_t *rowptr, const int32_t *col, int 
         if (next > max_slots) { where = first_where; clashes = first_clashes; nslots = s0; break; }
         nslots = next;
     }
+    // Small graphs: when holes were needed, the block count is set by how many COLOURS the graph needs, not by n / slot,
+    // and the balanced greedy pass wastes some (10 blocks for a 342-cell cluster that 8 colour).  A saturation-degree
+    // colouring (DSATUR: always the uncoloured variable that sees the most colours, ties by degree, then index; lowest
+    // colour with a free seat) is tried as well, and kept when it needs fewer blocks -- every block is a dependent step
+    // of a sweep, so 8 instead of 10 is 20 % of a small model's kernel time.  O(n^2): graphs up to 4096 variables.
+    if (clashes == 0 && nslots > s0 && n <= 4096) {
+        const int C = nslots;                                        // only fewer colours than the greedy result are of interest
+        std::vector<unsigned char> seen((size_t)n * C, 0);
+        std::vector<int> sat((size_t)n, 0), colour((size_t)n, -1), fill2((size_t)C, 0);
+        int used = 0;
+        bool ok = true;
+        for (int step = 0; step < n && ok; ++step) {
+            int v = -1;
+            for (int u = 0; u < n; ++u) {
+                if (colour[(size_t)u] >= 0) continue;
+                if (v < 0) { v = u; continue; }
+                const int du = rowptr[u + 1] - rowptr[u], dv = rowptr[v + 1] - rowptr[v];
+                if (sat[(size_t)u] > sat[(size_t)v] || (sat[(size_t)u] == sat[(size_t)v] && du > dv)) v = u;
+            }
+            int c = 0;
+            while (c < C && (seen[(size_t)v * C + c] || fill2[(size_t)c] >= slot)) ++c;
+            if (c >= C) { ok = false; break; }
+            colour[(size_t)v] = c;
+            fill2[(size_t)c]++;
+            used = std::max(used, c + 1);
+            if (used >= C) { ok = false; break; }                    // no better than the greedy layout
+            for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+                const int u = col[e];
+                if (!seen[(size_t)u * C + c]) { seen[(size_t)u * C + c] = 1; sat[(size_t)u]++; }
+            }
+        }
+        if (ok && used < nslots && used >= s0) {
+            where = colour;
+            nslots = used;
+        }
+    }
     std::vector<int> seat((size_t)nslots, 0);
     for (int i = 0; i < n; ++i) pos[i] = (int64_t)where[(size_t)i] * slot + seat[(size_t)where[(size_t)i]]++;   // by index inside a slot
     *out_slots = nslots;
