@@ -546,7 +546,13 @@ def main():
                     "model": "bytes the kernel's loads request from L2: per 64-variable slot the packed adjacency "
                              "(%d x 64 x 8 B) + linear terms (256 B), once per wavefront (two replicas per wavefront in the "
                              "pair kernel), every slot of every sweep; peak = L2 aggregate (MI355X_MICROARCH.md)" % ell_width,
-                    "binding_resource": binding_resource(kernel_name, R, len(betas))}
+                    "binding_resource": binding_resource(kernel_name, R, len(betas)),
+                    "what_binds": "NOT this path: a timing-only build of the kernel without any adjacency traffic takes the same "
+                                  "time (profiles/r03_k2p_without_adjacency_traffic.txt), and 12 % fewer vector instructions "
+                                  "bought 2 % (profiles/r03_k2_binding.json against r02): the dependent chain of a 64-variable "
+                                  "slot (state write -> LDS gathers -> 16-deep fma chain -> compare -> ballot -> rounds) with two "
+                                  "wavefronts per SIMD -- 4096 replicas are four per SIMD however they are packed; three "
+                                  "wavefronts per SIMD (6144 replicas) give +14 % (DESIGN.md section 5)"}
     roofline.update({"kernel": kernel_name, "kernel_ms": launch_ms, "launches_per_step": launches,
                      "sweeps_per_launch": sweeps_per_launch, "kernel_ms_per_step": k_ms, "acceptance": accept})
     best_state = best[3]
