@@ -91,8 +91,9 @@ int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases
  * run the same chain): "variant" (dense, n <= 4096: 0 auto, 1 wave per replica, 2 workgroup + LDS ring, 3 MFMA,
  * 4 scheduled), "mfma_permille" (default 600: chunks of a long dense run that accept at least this share go to
  * the MFMA kernel; 0 = never), "chunk_sweeps" (32), "k2_pair" (structured binary: 0 auto, 1 two replicas per
- * wavefront, 2 one), "k2_split" (the few-replica kernel: 0 auto = its one-wavefront form for runs of up to "k2_split_max" (512)
- * replicas, 1 always when eligible -- 2 / 4 wavefronts per replica on models laid out in edge-free blocks of 128 / 256 seats --, 2 never), "xl_batched" (dense, n > 4096: 0 auto = all replicas together on the matrix cores from 256
+ * wavefront, 2 one), "k2_split" (the few-replica kernels: 0 auto = runs of up to "k2_split_max" (1024) replicas, 1 always when
+ * eligible, 2 never; on models laid out in edge-free blocks of 128 / 256 seats "k2_wide" picks between ONE wavefront
+ * sweeping a whole block per step (0 / 1, the default) and a workgroup of 2 / 4 wavefronts doing it (2)), "xl_batched" (dense, n > 4096: 0 auto = all replicas together on the matrix cores from 256
  * replicas or n = 16384 up, 1 always, 2 a workgroup per replica), "xl_chain" (0 auto = the decisions and small passes of a group of eight blocks as one launch up to 512
  * replicas, 1 = one launch per block, 2 = fused always), "xl_chunk" (8) / "xl_cold_permille" (20): that batched kernel
  * hands a cooling run over to the per-replica kernel when a chunk of sweeps accepted less than this share.

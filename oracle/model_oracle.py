@@ -153,7 +153,7 @@ def padded_slot_layout(rowptr, col, slot=64, max_slots=None):
     """Restatement of mi_sa_plan_slot_layout: the greedy pass of ``slot_independent_order`` with ``nslots`` blocks of
     ``slot`` seats each (no short last block), repeated with nslots = ceil(n / slot), then + max(1, nslots // 8) per
     try, until no variable shares a block with a neighbour; beyond ``max_slots`` the packed result stands; when holes were
-    needed a DSATUR colouring is tried too and kept if it needs fewer blocks (graphs up to 4096 variables).  Returns
+    needed a DSATUR colouring is tried too and kept if it needs fewer blocks (graphs up to 2048 variables).  Returns
     (pos, nslots, clashes): pos[i] = block * slot + rank of i inside its block (by original index)."""
     import numpy as np
     rowptr = np.asarray(rowptr)
@@ -195,7 +195,7 @@ def padded_slot_layout(rowptr, col, slot=64, max_slots=None):
             nslots = s0
             break
         nslots = nxt
-    if clashes == 0 and nslots > s0 and n <= 4096:
+    if clashes == 0 and nslots > s0 and n <= 2048:
         # small graphs: a saturation-degree colouring (DSATUR; ties by degree, then index; lowest colour with a free seat),
         # kept when it needs fewer blocks than the greedy layout
         C = nslots

@@ -213,7 +213,8 @@ struct mi_sa_problem {
     int opt_k2_waves = 0;                    // K2: replicas per workgroup (0 = auto)
     int opt_k2_pair = 0;                     // K2p: 0 auto (runs of more replicas than the chip has SIMDs), 1 always when eligible, 2 never
     int opt_k2_split = 0;                    // K2s (csrc/sparse_split_kernels.hip): 0 auto (few replicas: its one-wavefront form), 1 always when eligible (2 / 4 wavefronts per replica on models laid out in blocks of 128 / 256 seats), 2 never
-    int opt_k2_split_max = 512;              // ... auto: runs of up to this many replicas (fewer wavefronts than half the chip's SIMDs)
+    int opt_k2_wide = 0;                     // models laid out in blocks of 128 / 256 seats, few replicas: 0 / 1 one wavefront sweeps a block per step (K2w), 2 a workgroup of 2 / 4 wavefronts does (K2s)
+    int opt_k2_split_max = 1024;             // ... auto: runs of up to this many replicas (a wavefront per SIMD at most)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
     int last_launches = 1;                   // kernel launches that served the last anneal
@@ -663,8 +664,8 @@ static int plan_slot_layout_impl(const int32_t *rowptr, const int32_t *col, int 
     // and the balanced greedy pass wastes some (10 blocks for a 342-cell cluster that 8 colour).  A saturation-degree
     // colouring (DSATUR: always the uncoloured variable that sees the most colours, ties by degree, then index; lowest
     // colour with a free seat) is tried as well, and kept when it needs fewer blocks -- every block is a dependent step
-    // of a sweep, so 8 instead of 10 is 20 % of a small model's kernel time.  O(n^2): graphs up to 4096 variables.
-    if (clashes == 0 && nslots > s0 && n <= 4096) {
+    // of a sweep, so 8 instead of 10 is 20 % of a small model's kernel time.  O(n^2): graphs up to 2048 variables.
+    if (clashes == 0 && nslots > s0 && n <= 2048) {
         const int C = nslots;                                        // only fewer colours than the greedy result are of interest
         std::vector<unsigned char> seen((size_t)n * C, 0);
         std::vector<int> sat((size_t)n, 0), colour((size_t)n, -1), fill2((size_t)C, 0);
@@ -877,6 +878,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "k2_pair") && value >= 0 && value <= 2) { p->opt_k2_pair = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_split") && value >= 0 && value <= 2) { p->opt_k2_split = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_split_max") && value >= 0) { p->opt_k2_split_max = (int)value; return MI_OK; }
+    if (!strcmp(key, "k2_wide") && value >= 0 && value <= 2) { p->opt_k2_wide = (int)value; return MI_OK; }
     if (!strcmp(key, "min_cluster_size") && value >= 0) {
         if (p->kind != MI_KIND_POTTS_CSR) return fail(MI_EINVAL, "min_cluster_size applies to Potts problems");
         p->opt_min_cluster_size = (int)value;
@@ -1027,9 +1029,13 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
             int choice = 0;
             if (p->opt_k2_split == 1 && split_ok) choice = 2;
             else if (p->opt_k2_pair == 1 && pair_ok) choice = 1;
-            else if (p->opt_k2_split != 2 && split_ok && p->k2_free_block == 64 && R <= p->opt_k2_split_max) choice = 2;
+            else if (p->opt_k2_split != 2 && split_ok && R <= p->opt_k2_split_max) choice = 2;
             else if (p->opt_k2_pair != 2 && pair_ok && R > 1024) choice = 1;
-            if (choice == 2) {
+            if (choice == 2 && p->k2_free_block > 64 && p->opt_k2_wide != 2 && (p->D == 16 || p->k2_free_block == 128)) {
+                // blocks of 128 / 256 edge-free seats, few replicas: ONE wavefront sweeps a block per step
+                a.adj4 = p->d_adj4p;
+                rc = mi_launch_csr_rank1_wide(a, p->k2_free_block / 64, p->stream);
+            } else if (choice == 2) {
                 a.adj4 = p->d_adj4p;
                 rc = mi_launch_csr_rank1_split(a, p->k2_free_block / 64, p->stream);
             } else if (choice == 1) {

@@ -390,6 +390,235 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
     if (lane == 0) atomicAdd(&a.stats[1], accepted);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2w: ONE wavefront per replica, SPB slots per step
+// ------------------------------------------------------------------------------------------------
+// The other way to use an edge-free block of 64 SPB seats (SPB = 2, 4) when replicas are few: one wavefront sweeps the
+// whole block in one step -- the LDS reads of all its slots issued together, their field sums as SPB independent fma
+// chains, their thresholds side by side (two at a time as packed arithmetic), and only the accept masks in sequence
+// (slot j + 1 sees the sum slot j leaves).  A wavefront that is alone on its SIMD spends a slot of k_anneal_csr_rank1
+// mostly WAITING (115 instructions in 950 cycles: LDS round trip, the 16-deep fma chain, vector -> scalar -> vector
+// hops); two or four slots' worth of independent work per step fill those gaps, with no exchange between wavefronts.
+// Same chain as every other kernel of the family on the same padded model, bit for bit.
+template <int D, int SPB>
+__global__ void __launch_bounds__(64, 1) k_anneal_csr_rank1_wide(EllArgs a)
+{
+    static_assert(SPB == 2 || SPB == 4, "two or four slots per step");
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // one 32-bit cell per seat, low half = x (0.0 / 1.0)
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x;
+    const uint32_t gid = a.replica_offset + (uint32_t)r;
+    const int n = a.n, slots = a.slots, blocks = slots / SPB;       // slots is a multiple of SPB (launcher)
+    const uint8_t *init = static_cast<const uint8_t *>(a.init);
+
+    int S = 0;
+    for (int t = 0; t < slots; ++t) {
+        const int i = t * 64 + lane;
+        bool x;
+        const bool real = i < n && a.lin[i] < INFINITY;            // (+inf linear term = hole of a padded layout: stays 0)
+        if (init) {
+            x = real && init[(size_t)r * n + i] != 0;
+        } else {
+            uint32_t iw[4];
+            philox4x32_10((uint32_t)((t >> 2) * 64 + lane), 0u, gid, 1u, a.seed_lo, a.seed_hi, iw);
+            const int c = t & 3;
+            x = real && ((c == 0 ? iw[0] : (c == 1 ? iw[1] : (c == 2 ? iw[2] : iw[3]))) >> 31);
+        }
+        reinterpret_cast<uint32_t *>(lds)[i] = x ? 0x3c00u : 0u;
+        S += __popcll(__ballot(x));
+    }
+
+    constexpr int G = D / 4;
+    const __amdgpu_buffer_rsrc_t rs_adj = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(a.adj4), 0, slots * G * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.lin), 0, slots * 256, 0x00020000);
+    struct SlotAdj { u32x4 col[G]; u32x4 val[G]; uint32_t lin; };
+    struct BlockAdj { SlotAdj s[SPB]; };
+    auto fetch_block = [&](int b) {                                 // the pair kernel's packing: neighbour word = 4 * index
+        BlockAdj p;
+        const int bb = b < blocks ? b : blocks - 1;
+#pragma unroll
+        for (int j = 0; j < SPB; ++j) {
+            const int tt = bb * SPB + j;
+            const int soff = tt * (G * 2048);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int so = soff + (g / 2) * 4096, io = (g & 1) * 2048;
+                p.s[j].col[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16 + io, so, 0);
+                p.s[j].val[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, lane * 16 + io + 1024, so, 0);
+            }
+            p.s[j].lin = __builtin_amdgcn_raw_buffer_load_b32(rs_lin, lane * 4, tt * 256, 0);
+        }
+        return p;
+    };
+
+    unsigned long long accepted = 0;
+    float T = 1.0f;
+    const float cp = a.c_pair;
+    uint32_t sw = a.sweep_offset;
+    // random words: `cw` = the four words of the group the step is in, `nx` = the next group's block in the making
+    // (10 SPB / 4 rounds per step under the gathers; a short last group's remainder is finished when the group changes)
+    uint32_t cw[4] = {0u, 0u, 0u, 0u};
+    PhiloxPipe nx;
+    int cur_g = -1;
+    nx.start((uint32_t)lane, sw, gid, 0u, a.seed_lo, a.seed_hi);
+
+    auto step = [&](int b, const BlockAdj &cur) {
+        const int t0 = b * SPB;
+        if ((t0 >> 2) != cur_g) {                                   // wave-uniform: this block opens a new group of four slots
+            while (nx.done < 10) nx.round();
+            cw[0] = nx.c0; cw[1] = nx.c1; cw[2] = nx.c2; cw[3] = nx.c3;
+            cur_g = t0 >> 2;
+            const int tn = ((t0 >> 2) + 1) * 4;                     // first slot of the next group, or of the next sweep
+            const bool wrap = tn >= slots;
+            nx.start((uint32_t)((wrap ? 0 : (tn >> 2)) * 64 + lane), wrap ? sw + 1u : sw, gid, 0u, a.seed_lo, a.seed_hi);
+        }
+        // (1) the LDS reads of all SPB slots (at most 16 stay in flight; the issue of the later ones paces itself)
+        uint32_t own[SPB], word[SPB][16];
+#pragma unroll
+        for (int j = 0; j < SPB; ++j) {
+            asm volatile("ds_read_b32 %0, %1" : "=v"(own[j]) : "v"(((t0 + j) * 64 + lane) * 4) : "memory");
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                asm volatile("ds_read_b32 %0, %1" : "=v"(word[j][k]) : "v"(cur.s[j].col[k / 4][k & 3]));
+        }
+        // (2) behind their issue: the SPB thresholds (pairs of them as packed arithmetic) and a share of the next random words
+        uint32_t rw[SPB];
+#pragma unroll
+        for (int j = 0; j < SPB; ++j) {
+            const int c = (t0 + j) & 3;                             // (SPB = 4: c = j; SPB = 2: 0, 1 or 2, 3)
+            rw[j] = c == 0 ? cw[0] : (c == 1 ? cw[1] : (c == 2 ? cw[2] : cw[3]));
+        }
+        asm volatile("" : "+v"(rw[0]), "+v"(rw[1]), "+v"(nx.c0), "+v"(nx.c1), "+v"(nx.c2), "+v"(nx.c3));
+        float thr[SPB];
+#pragma unroll
+        for (int j = 0; j < SPB; j += 2) {
+            const f32x2_t l2 = neglog_u2(rw[j], rw[j + 1]) * f32x2_t{T, T};
+            thr[j] = l2.x;
+            thr[j + 1] = l2.y;
+        }
+#pragma unroll
+        for (int k = 0; k < (10 * SPB) / 4; ++k) nx.round();        // (a group lasts 4 / SPB steps: never past ten rounds)
+        // (3) the field sums: SPB independent chains
+        float gi[SPB];
+#pragma unroll
+        for (int j = 0; j < SPB; ++j) gi[j] = __uint_as_float(cur.s[j].lin);
+#pragma unroll
+        for (int g0 = 0; g0 < G; g0 += 4) {
+            if (g0 > 0) {
+#pragma unroll
+                for (int j = 0; j < SPB; ++j)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(word[j][k]) : "v"(cur.s[j].col[g0 + k / 4][k & 3]));
+            }
+#pragma unroll
+            for (int j = 0; j < SPB; ++j) {
+                // slot j's reads are older than slot j + 1's: everything but the 17 (SPB - 1 - j) youngest has returned
+                // (the hardware counter holds 15 at most, so for the early slots this is a full wait in effect)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(word[j][0]), "+v"(word[j][1]), "+v"(word[j][2]), "+v"(word[j][3]), "+v"(word[j][4]),
+                               "+v"(word[j][5]), "+v"(word[j][6]), "+v"(word[j][7]), "+v"(word[j][8]), "+v"(word[j][9]),
+                               "+v"(word[j][10]), "+v"(word[j][11]), "+v"(word[j][12]), "+v"(word[j][13]), "+v"(word[j][14]),
+                               "+v"(word[j][15]), "+v"(own[j]), "+v"(thr[j])
+                             :: "memory");
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int j = 0; j < SPB; ++j) {
+                    const half_t hx = __builtin_bit_cast(half_t, (uint16_t)word[j][k]);
+                    gi[j] = __builtin_fmaf(__uint_as_float(cur.s[j].val[g0 + k / 4][k & 3]), (float)hx, gi[j]);   // fma(val, x, g)
+                }
+        }
+        // (4) the accept masks, slot after slot (k_anneal_csr_rank1's rounds); the block holds no edge, so a later slot's
+        // field sum does not see an earlier slot's flips -- only the sum does
+#pragma unroll
+        for (int j = 0; j < SPB; ++j) {
+            const int i = (t0 + j) * 64 + lane;
+            const uint64_t X = __ballot(own[j] != 0u);
+            const uint32_t xi = own[j] >> 13;                       // 0x3c00 -> 1
+            const uint32_t sgnbit = xi << 31;                       // dE = x ? -f : f
+            const float gs = __uint_as_float(__float_as_uint(gi[j]) ^ sgnbit);
+            const float cs = __uint_as_float(__float_as_uint(cp) ^ sgnbit);
+            uint64_t A = __ballot(gs + cs * (float)(S - (int)xi) < thr[j]);
+            if (A != 0ull) {                                        // wave-uniform
+                const int base = S - (int)xi - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(X >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)X, 0u));
+                for (int round = 0; round < 66; ++round) {
+                    const uint64_t Bm = A ^ X;
+                    const int s_i = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(Bm >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)Bm, (uint32_t)base));
+                    const uint64_t A2 = __ballot(gs + cs * (float)s_i < thr[j]);
+                    if (A2 == A) break;
+                    A = A2;
+                }
+                if ((A >> lane) & 1ull) asm volatile("ds_write_b32 %0, %1" :: "v"(i * 4), "v"(own[j] ^ 0x3c00u) : "memory");
+                S += __popcll(A & ~X) - __popcll(A & X);
+                accepted += (unsigned long long)__popcll(A);
+            }
+        }
+    };
+
+    for (int s = 0; s < a.num_sweeps; ++s) {
+        T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[a.temps_per_replica ? r : s])));
+        sw = (uint32_t)s + a.sweep_offset;
+        cur_g = -1;
+        BlockAdj P = fetch_block(0), Q;
+#pragma unroll 1
+        for (int b = 0; b < blocks; b += 2) {
+            Q = fetch_block(b + 1);
+            step(b, P);
+            if (b + 1 < blocks) {                                   // wave-uniform
+                P = fetch_block(b + 2);
+                step(b + 1, Q);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- epilogue: states out, exact fp64 energy (the sums of k_anneal_csr_rank1) ----
+    uint8_t *dst = static_cast<uint8_t *>(a.states) + (size_t)r * n;
+    const uint32_t *cell = reinterpret_cast<const uint32_t *>(lds);
+    int cnt = 0;
+    double e = 0.0;
+    for (int t = 0; t < slots; ++t) {
+        const int i = t * 64 + lane;
+        const bool on = cell[i] != 0u;
+        if (i < n) dst[i] = (uint8_t)on;
+        cnt += __popcll(__ballot(on));
+        if (!on) continue;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) {
+            const size_t at = ((size_t)t * D + k) * 64 + lane;
+            const uint32_t cc = a.ell_col[at];
+            const double vv = a.ell_val64 ? a.ell_val64[at] : (double)a.ell_val[at];
+            if (cell[cc] != 0u) acc += vv;
+        }
+        e += (a.lin64 ? a.lin64[i] : (double)a.lin[i]) + 0.5 * acc;
+    }
+    e = wave_sum_f64(e);
+    if (lane == 0) {
+        const double cp64 = a.ell_val64 ? a.c_pair64 : (double)a.c_pair;
+        a.energy[r] = e + cp64 * 0.5 * (double)cnt * (double)(cnt - 1) + a.offset;
+        atomicAdd(&a.stats[1], accepted);
+    }
+}
+
+template <typename KernelT>
+int launch_wide(KernelT kernel, const EllArgs &a, int spb, hipStream_t st)
+{
+    const size_t lds = (size_t)a.slots * 256;
+    if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1 wide kernel: n = %d exceeds the state LDS budget", a.n);
+    if (a.slots % spb != 0) return fail(MI_EINVAL, "csr_rank1 wide kernel: %d slots are not whole blocks of %d", a.slots, spb);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    note_kernel("k_anneal_csr_rank1_wide<%d, %d>", a.D, spb);
+    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(64), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 template <typename KernelT>
 int launch_split(KernelT kernel, const EllArgs &a, int nw, hipStream_t st)
 {
@@ -407,6 +636,17 @@ int launch_split(KernelT kernel, const EllArgs &a, int nw, hipStream_t st)
 }
 
 }  // namespace
+
+// one wavefront per replica, spb = 2 / 4 slots per step (a model whose every block of 64 * spb seats is free of internal
+// edges; a.adj4 = the pair kernel's packing)
+int mi_launch_csr_rank1_wide(const EllArgs &a, int spb, hipStream_t st)
+{
+    if (!a.adj4) return fail(MI_EHIP, "csr_rank1 wide kernel: packed adjacency missing");
+    if (a.D == 16 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<16, 2>, a, spb, st);
+    if (a.D == 16 && spb == 4) return launch_wide(k_anneal_csr_rank1_wide<16, 4>, a, spb, st);
+    if (a.D == 32 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<32, 2>, a, spb, st);
+    return fail(MI_EUNSUPPORTED, "csr_rank1 wide kernel: width %d / %d slots per step not built", a.D, spb);
+}
 
 // a.adj4 must hold the pair kernel's packing (neighbour word = 4 * index) of a model whose every block of 64 * nw seats
 // is free of internal edges

@@ -12,16 +12,21 @@ from . import _lib
 _POTTS_MAX_N = 40000          # mi_sa_problem_create_potts_csr_f32's limit
 
 
-def layout_block_for(n: int, num_reads: int, max_degree: int = 16) -> int:
-    """Seats per edge-free block the sampler lays a structured binary model out in.  64 = one wavefront sweeps a block.
-    128 / 256 lay the model out for the workgroup-per-replica kernel (csrc/sparse_split_kernels.hip: 2 / 4 wavefronts
-    sweep a block together, a sweep is slots / 2 or / 4 dependent steps).  Measured on the MI355X (500 reads x 1000
-    sweeps, n = 2638; profiles/r03_split_kernel.txt): 16.4 ms with four wavefronts per replica against 17.7 ms with
-    one -- a step of four slots costs 2200 cycles where four steps of one cost 3900, but the wavefronts of a CU then
-    issue their LDS gathers in bursts (850 cycles until the last is accepted), the exchange of their net changes takes
-    650, and in the hot third of a schedule a block needs two to four of them.  8 %: the sampler keeps 64-seat blocks
-    at every size; the wider layouts stay available to callers (``block=`` + option ``k2_split`` = 1)."""
-    return 64
+def layout_block_for(n: int, num_reads: int, max_degree: int = 16):
+    """Seats per edge-free block the sampler lays a structured binary model out in: 64 (one wavefront sweeps a slot per
+    step), or ``"auto"`` for the few reads the reference asks for (``num_reads = 500``, BQM_clustering.py:52), where
+    every wavefront has a SIMD to itself and a run takes (steps per sweep) x (one wavefront's time per step):
+    ``Problem.csr_rank1`` then plans the 64-seat AND the 128-seat layout and takes the wider one when it needs few
+    enough blocks -- one wavefront sweeps such a block per step (K2w, csrc/sparse_split_kernels.hip: 1540 cycles for
+    two slots against 2 x 955) -- which large sparse graphs do (n = 2638: 22 blocks against 42 slots) and small or
+    clustered ones, whose block count is set by the colours they need, do not."""
+    if num_reads > 1024 or max_degree > 32 or n > 4608 or n < 1024:      # (below ~1000 variables the colours decide)
+        return 64
+    return "auto"
+
+
+# a two-slot step of the wide kernel costs 1540 cycles, a one-slot step 955 (MI355X, a wavefront alone on its SIMD)
+_WIDE_STEP_RATIO = 1540.0 / 955.0
 
 
 def _ptr(a, ctype):
@@ -63,7 +68,7 @@ class Problem:
 
     @classmethod
     def csr_rank1(cls, rowptr, col, val, lin, c_pair: float, offset: float = 0.0,
-                  device: int = 0, order: Optional[str] = None, energy_model=None, block: int = 64) -> "Problem":
+                  device: int = 0, order: Optional[str] = None, energy_model=None, block=64) -> "Problem":
         """``order="slots"`` renumbers the variables on the device so that the 64 variables a wavefront
         sweeps together are (as far as possible) mutually non-adjacent -- the kernel's integer fast path
         (models.slot_independent_order).  States go in and come out in the CALLER's order either way; the
@@ -72,10 +77,11 @@ class Problem:
         between blocks (models.padded_slot_layout); what small or strongly clustered graphs need (the subgraphs of the
         reference's recursive bisection, its 256-node benchmark graphs), where no packed order is edge-free.
 
-        ``block`` (64, 128 or 256; ``order="padded"`` only): seats per edge-free block.  128 / 256 lay the model out for
-        the few-replica kernel (a workgroup of 2 / 4 wavefronts sweeps one replica, a sweep takes slots / 2 or / 4
-        dependent steps: csrc/sparse_split_kernels.hip), which the library then picks for runs of up to 1024 replicas;
-        ``layout_block_for`` is the sampler's choice.
+        ``block`` (64, 128, 256 or "auto"; ``order="padded"`` only): seats per edge-free block.  128 / 256 lay the model
+        out for the few-replica kernels (csrc/sparse_split_kernels.hip: one wavefront sweeps a whole block per step, K2w,
+        or -- option ``k2_wide`` = 2 -- a workgroup of 2 / 4 wavefronts does, K2s), which the library picks for runs of up
+        to 1024 replicas; "auto" plans both the 64- and the 128-seat layout and keeps the faster; ``layout_block_for`` is
+        the sampler's choice.
 
         ``energy_model=(val64, lin64, c_pair64)``: the caller's fp64 coefficients (same CSR structure); the
         reported energies are then evaluated on the device in that model (the chain itself runs in fp32)."""
@@ -95,8 +101,14 @@ class Problem:
             # A hole is a variable without couplings whose linear term is +inf: the kernels start it at 0 and
             # never flip it; its fp64 energy coefficients are 0.
             from .models import pad_csr, padded_slot_layout
+            if block == "auto":
+                # both layouts planned (a millisecond each); the 128-seat one when its steps take less time in all
+                s64 = padded_slot_layout(rowptr, col, slot=64)
+                s128 = padded_slot_layout(rowptr, col, slot=128)
+                wide = s128[2] == 0 and s64[2] == 0 and (s128[1] + (s128[1] & 1)) * _WIDE_STEP_RATIO < s64[1]
+                block = 128 if wide else 64
             if block not in (64, 128, 256):
-                raise ValueError("block must be 64, 128 or 256")
+                raise ValueError("block must be 64, 128, 256 or 'auto'")
             seats, nslots, clashes = padded_slot_layout(rowptr, col, slot=block)
             if block > 64 and clashes:               # no edge-free layout in blocks this wide: the 64-seat layout
                 return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "padded", energy_model)

@@ -257,12 +257,19 @@ def test_few_replica_kernel_workgroup_per_replica(case):
     with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), c_pair, order="padded", block=block,
                            energy_model=(m.val, m.lin, m.c_pair)) as p:
         assert p.n == n and p.n_dev == N
-        if block > 64:
-            p.set_option("k2_split", 1)
         p.anneal(R, betas, 8, replica_offset=3)
         name = p.kernel_name()
-        assert name.startswith("k_anneal_csr_rank1_split<") and name.endswith(", %d>" % (block // 64)), name
+        # few replicas: blocks of 64 -> K2s with one wavefront; wider blocks -> K2w, ONE wavefront sweeping 2 / 4 slots per step
+        assert name.startswith("k_anneal_csr_rank1_split<" if block == 64 else "k_anneal_csr_rank1_wide<"), name
+        assert name.endswith(", %d>" % (block // 64)), name
         st, en, info = p.fetch()
+        if block > 64:                                 # ... and on request K2s with 2 / 4 wavefronts per replica: the same run
+            p.set_option("k2_wide", 2)
+            p.anneal(R, betas, 8, replica_offset=3)
+            assert p.kernel_name().startswith("k_anneal_csr_rank1_split<") and p.kernel_name().endswith(", %d>" % (block // 64))
+            sw_, ew_, iw_ = p.fetch()
+            assert np.array_equal(sw_, st) and np.allclose(ew_, en, rtol=1e-13) and iw_["accepted"] == info["accepted"]
+            p.set_option("k2_wide", 0)
         assert np.array_equal(st, o_rand[0][:, pos]) and info["accepted"] == int(o_rand[2][1])
         assert info["proposals"] == R * len(betas) * n and np.allclose(en, m.energies(st), rtol=1e-12)
         i_best, e_best, _, s_best = p.best()
@@ -292,7 +299,8 @@ def test_few_replica_kernel_workgroup_per_replica(case):
         p.set_option("k2_split", 1)
         p.anneal(R, betas[:0], 8, initial_states=init)
         s0, e0, _ = p.fetch()
-        assert "split" in p.kernel_name() and np.array_equal(s0, init) and np.allclose(e0, m.energies(init), rtol=1e-12)
+        assert ("split" in p.kernel_name() or "wide" in p.kernel_name()) and np.array_equal(s0, init)
+        assert np.allclose(e0, m.energies(init), rtol=1e-12)
 
 
 def test_potts_padded_layout_of_a_clustered_subgraph():
