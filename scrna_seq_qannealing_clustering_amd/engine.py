@@ -93,8 +93,10 @@ class Problem:
             from .models import permute_csr, slot_independent_order
             perm = slot_independent_order(rowptr, col)
             if val64 is not None:
-                val64, lin64 = permute_csr(rowptr, col, val64, perm)[2], lin64[perm]
-            rowptr, col, val = permute_csr(rowptr, col, val, perm)
+                rowptr, col, val, val64 = permute_csr(rowptr, col, val, perm, also=val64)
+                lin64 = lin64[perm]
+            else:
+                rowptr, col, val = permute_csr(rowptr, col, val, perm)
             lin = np.asarray(lin)[perm]
         elif order == "padded":
             # seats with holes (models.padded_slot_layout): the fewest blocks of 64 that keep every edge BETWEEN blocks.
@@ -107,9 +109,11 @@ class Problem:
                 s128 = padded_slot_layout(rowptr, col, slot=128)
                 wide = s128[2] == 0 and s64[2] == 0 and (s128[1] + (s128[1] & 1)) * _WIDE_STEP_RATIO < s64[1]
                 block = 128 if wide else 64
-            if block not in (64, 128, 256):
+                seats, nslots, clashes = s128 if wide else s64
+            elif block in (64, 128, 256):
+                seats, nslots, clashes = padded_slot_layout(rowptr, col, slot=block)
+            else:
                 raise ValueError("block must be 64, 128, 256 or 'auto'")
-            seats, nslots, clashes = padded_slot_layout(rowptr, col, slot=block)
             if block > 64 and clashes:               # no edge-free layout in blocks this wide: the 64-seat layout
                 return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "padded", energy_model)
             if block == 128 and nslots % 2:          # (the two-wavefront kernel takes whole groups of four 64-seat slots)
@@ -118,11 +122,12 @@ class Problem:
             if n_dev > (1 << 20) >= n_caller:        # the holes would push the model over the kernel's size limit
                 return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "slots", energy_model)
             if val64 is not None:
-                val64 = pad_csr(rowptr, col, val64, seats, n_dev)[2]
+                rowptr, col, val, val64 = pad_csr(rowptr, col, val, seats, n_dev, also=val64)     # (one sort for both)
                 l64 = np.zeros(n_dev, dtype=np.float64)
                 l64[seats] = lin64
                 lin64 = l64
-            rowptr, col, val = pad_csr(rowptr, col, val, seats, n_dev)
+            else:
+                rowptr, col, val = pad_csr(rowptr, col, val, seats, n_dev)
             lpad = np.full(n_dev, np.inf, dtype=np.float32)
             lpad[seats] = np.asarray(lin, dtype=np.float32)
             lin = lpad
@@ -158,8 +163,9 @@ class Problem:
             from .models import permute_csr, slot_independent_order
             perm = slot_independent_order(rowptr, col)
             if val64 is not None:
-                val64 = permute_csr(rowptr, col, val64, perm)[2]
-            rowptr, col, val = permute_csr(rowptr, col, val, perm)
+                rowptr, col, val, val64 = permute_csr(rowptr, col, val, perm, also=val64)
+            else:
+                rowptr, col, val = permute_csr(rowptr, col, val, perm)
         elif order == "padded":
             # seats with holes, as in csr_rank1; a hole of a Potts model is marked through mi_sa_problem_set_absent:
             # label 0, in no cluster, never proposed
@@ -170,8 +176,9 @@ class Problem:
                 return cls.potts_csr(rowptr, col, val, c_pair, n, num_cases, lin_offset, device, "slots", energy_model)
             n_caller, n = int(n), nslots * 64
             if val64 is not None:
-                val64 = pad_csr(rowptr, col, val64, seats, n)[2]
-            rowptr, col, val = pad_csr(rowptr, col, val, seats, n)
+                rowptr, col, val, val64 = pad_csr(rowptr, col, val, seats, n, also=val64)
+            else:
+                rowptr, col, val = pad_csr(rowptr, col, val, seats, n)
         elif order is not None:
             raise ValueError("order must be None, 'slots' or 'padded'")
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)

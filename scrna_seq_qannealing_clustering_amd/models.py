@@ -526,30 +526,42 @@ def padded_slot_layout(rowptr: np.ndarray, col: np.ndarray, slot: int = 64, max_
     return pos, int(slots.value), int(clashes.value)
 
 
-def pad_csr(rowptr, col, val, pos, n_dev: int):
-    """CSR of the same symmetric matrix with variable ``i`` moved to seat ``pos[i]`` of ``n_dev`` seats; the other seats are
-    holes (empty rows).  Rows keep their neighbours in ascending NEW index order (as ``permute_csr``)."""
-    pos = np.asarray(pos, dtype=np.int64)
-    rows_old = np.repeat(np.arange(len(pos)), np.diff(rowptr))
-    r_new, c_new = pos[rows_old], pos[np.asarray(col)]
-    order = np.lexsort((c_new, r_new))
-    counts = np.bincount(r_new, minlength=n_dev)
+def _reseat_order(rowptr, col, new_of_old, n_dev: int):
+    """``(rowptr_new, col_new, order)`` of a CSR whose variable ``i`` moves to index ``new_of_old[i]`` of ``n_dev``: rows in
+    new index order, neighbours ascending by new index; ``order`` gathers any per-entry array into the new entry order.
+    One sort of a combined 64-bit key (row * n_dev + column)."""
+    new_of_old = np.asarray(new_of_old, dtype=np.int64)
+    deg = np.diff(rowptr)
+    rows_old = np.repeat(np.arange(len(new_of_old)), deg)
+    key = new_of_old[rows_old] * np.int64(n_dev) + new_of_old[np.asarray(col)]
+    order = np.argsort(key, kind="stable")
+    cnt = np.zeros(n_dev, dtype=np.int64)
+    cnt[new_of_old] = deg
     rp = np.zeros(n_dev + 1, dtype=np.int32)
-    rp[1:] = np.cumsum(counts)
-    return rp, c_new[order].astype(np.int32), np.asarray(val)[order]
+    rp[1:] = np.cumsum(cnt)
+    return rp, (key[order] % n_dev).astype(np.int32), order
 
 
-def permute_csr(rowptr, col, val, perm):
+def pad_csr(rowptr, col, val, pos, n_dev: int, also=None):
+    """CSR of the same symmetric matrix with variable ``i`` moved to seat ``pos[i]`` of ``n_dev`` seats; the other seats are
+    holes (empty rows).  Rows keep their neighbours in ascending NEW index order (as ``permute_csr``).  ``also``: a second
+    per-entry array (the fp64 coefficients of the energy model) carried through the same reordering -- returned fourth."""
+    rp, c, order = _reseat_order(rowptr, col, pos, n_dev)
+    if also is None:
+        return rp, c, np.asarray(val)[order]
+    return rp, c, np.asarray(val)[order], np.asarray(also)[order]
+
+
+def permute_csr(rowptr, col, val, perm, also=None):
     """CSR of the same symmetric matrix with variables renumbered by ``perm`` (``perm[new] = old``); rows keep
-    their neighbours in ascending NEW index order."""
+    their neighbours in ascending NEW index order.  ``also``: as in :func:`pad_csr`."""
     n = len(perm)
     inv = np.empty(n, dtype=np.int64)
     inv[perm] = np.arange(n)
-    rows_old = np.repeat(np.arange(n), np.diff(rowptr))
-    r_new, c_new = inv[rows_old], inv[np.asarray(col)]
-    order = np.lexsort((c_new, r_new))
-    out_ptr = np.concatenate([[0], np.cumsum(np.bincount(r_new, minlength=n))]).astype(np.int32)
-    return out_ptr, c_new[order].astype(np.int32), np.asarray(val)[order]
+    rp, c, order = _reseat_order(rowptr, col, inv, n)
+    if also is None:
+        return rp, c, np.asarray(val)[order]
+    return rp, c, np.asarray(val)[order], np.asarray(also)[order]
 
 
 def add_size_window_penalty(model: QuboModel, lb: float, ub: float, lagrange_multiplier: float,
