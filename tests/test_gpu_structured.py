@@ -303,6 +303,69 @@ def test_few_replica_kernel_workgroup_per_replica(case):
         assert np.allclose(e0, m.energies(init), rtol=1e-12)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_few_replica_kernels_random_models(seed):
+    """Random sparse models (size, degree, weights, schedule, replica count and offset drawn per seed) laid out in
+    edge-free blocks of 64 / 128 / 256 seats and run on the few-replica kernels -- K2s with 1, 2 or 4 wavefronts per
+    replica, K2w with 2 or 4 slots per step -- against the oracle on the same padded model: states, accepted counts,
+    energies; random initial states from the replica's own stream and given ones."""
+    rs = np.random.RandomState(5000 + seed)
+    n = int(rs.choice([70, 130, 257, 700, 1300]))
+    max_deg = int(rs.choice([3, 9, 16, 17, 30]))
+    m_edges = min(n * max_deg // 3, n * (n - 1) // 2)
+    pairs = set()
+    deg = np.zeros(n, dtype=int)
+    for _ in range(4 * m_edges):
+        if len(pairs) >= m_edges:
+            break
+        a_, b_ = (int(x) for x in rs.randint(0, n, 2))
+        if a_ == b_ or (min(a_, b_), max(a_, b_)) in pairs or deg[a_] >= max_deg or deg[b_] >= max_deg:
+            continue
+        pairs.add((min(a_, b_), max(a_, b_)))
+        deg[a_] += 1
+        deg[b_] += 1
+    edges = sorted(pairs)
+    w = rs.choice(np.array([1 / 9, 0.25, 3 / 7, 2 / 3, 1.0, -0.5]), size=len(edges)).astype(np.float32)
+    rowptr, col, val = _csr_from_edges(n, edges, w)
+    lin = rs.normal(scale=0.7, size=n).astype(np.float32)
+    c_pair = float(np.float32(rs.choice([0.0, 0.03, 0.4, -0.02])))
+    sweeps = int(rs.choice([1, 4, 13, 30]))
+    betas = np.geomspace(float(rs.choice([0.05, 0.5])), float(rs.choice([2.0, 40.0])), sweeps)
+    R = int(rs.choice([1, 2, 7]))
+    off = int(rs.choice([0, 5, 2 ** 31 - 3]))
+    block = int(rs.choice([64, 128, 256]))
+    pos, nblocks, clashes = models.padded_slot_layout(rowptr, col, slot=block)
+    if clashes:
+        pytest.skip("no edge-free layout in blocks of %d for this graph" % block)
+    if block == 128 and nblocks % 2:
+        nblocks += 1
+    N = nblocks * block
+    rp, cc, vv = models.pad_csr(rowptr, col, val, pos, N)
+    lpad = np.full(N, np.inf, dtype=np.float32)
+    lpad[pos] = lin
+    init = rs.randint(0, 2, size=(R, n)).astype(np.uint8)
+    init_dev = np.zeros((R, N), dtype=np.uint8)
+    init_dev[:, pos] = init
+    o_rand = so.sa_csr_rank1_philox(rp, cc, vv, lpad, c_pair, R, betas, 7 + seed, replica_offset=off)
+    o_init = so.sa_csr_rank1_philox(rp, cc, vv, lpad, c_pair, R, betas, 7 + seed, replica_offset=off, init=init_dev)
+    with Problem.csr_rank1(rowptr, col, val, lin, c_pair, order="padded", block=block) as p:
+        for wide in ((0, 2) if block > 64 else (0,)):
+            p.set_option("k2_split", 1)
+            p.set_option("k2_wide", wide)
+            p.anneal(R, betas, 7 + seed, replica_offset=off)
+            name = p.kernel_name()
+            # K2w exists with two slots per step at either width and with four at 16 entries per variable
+            is_wide = block > 64 and wide == 0 and (int(deg.max()) <= 16 or block == 128)
+            assert ("wide<" in name) == is_wide and ("split<" in name) == (not is_wide), name
+            st, en, info = p.fetch()
+            assert np.array_equal(st, o_rand[0][:, pos]) and info["accepted"] == int(o_rand[2][1])
+            assert np.allclose(en, o_rand[1], rtol=1e-9, atol=1e-9)
+            p.anneal(R, betas, 7 + seed, replica_offset=off, initial_states=init)
+            st2, en2, info2 = p.fetch()
+            assert np.array_equal(st2, o_init[0][:, pos]) and info2["accepted"] == int(o_init[2][1])
+            assert np.allclose(en2, o_init[1], rtol=1e-9, atol=1e-9)
+
+
 def test_potts_padded_layout_of_a_clustered_subgraph():
     """K3 under order="padded": the holes (mi_sa_problem_set_absent) keep label 0, sit in no cluster -- the size penalty
     does not see them -- and are never proposed.  Equal to the oracle on the same padded model with the same positions
