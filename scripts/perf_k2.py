@@ -46,6 +46,11 @@ with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(n
                     print("   K2s cycles/step (wave 0): [adjacency wait + LDS reads issued %.0f, threshold + random words %.0f, rest of the gathers %.0f]  "
                           "sum %.0f  first solve %.0f  publish+barrier+read %.0f  further passes %.0f" % tuple(
                               float(x) / a.replicas / a.sweeps / steps for x in (ds[13], ds[6], ds[8], ds[9], ds[10], ds[11], ds[12])))
+                elif "pair" in p.kernel_name():
+                    slots = p.n_dev // 64
+                    print("   K2p cycles per slot pair (sweeping wavefront; s_memtime ticks): top+prefetch %.0f  gathers issued->arrived %.0f  "
+                          "field sums + first masks %.0f  rounds + commit %.0f  barrier %.0f" % tuple(
+                              float(x) / (a.replicas / 2) / a.sweeps / slots for x in (ds[8], ds[9], ds[10], ds[11], ds[12])))
                 else:
                     print("   phase cycles/wave/sweep: pre %.0f loop %.0f wait %.0f field-sum %.0f slot-top %.0f" % tuple(
                         float(x) / a.replicas / a.sweeps for x in ds[8:13]))

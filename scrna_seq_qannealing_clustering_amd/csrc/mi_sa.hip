@@ -214,6 +214,7 @@ struct mi_sa_problem {
     int opt_k2_pair = 0;                     // K2p: 0 auto (runs of more replicas than the chip has SIMDs), 1 always when eligible, 2 never
     int opt_k2_split = 0;                    // K2s (csrc/sparse_split_kernels.hip): 0 auto (few replicas: its one-wavefront form), 1 always when eligible (2 / 4 wavefronts per replica on models laid out in blocks of 128 / 256 seats), 2 never
     int opt_k2_wide = 0;                     // models laid out in blocks of 128 / 256 seats, few replicas: 0 / 1 one wavefront sweeps a block per step (K2w), 2 a workgroup of 2 / 4 wavefronts does (K2s)
+    int opt_k2_tw = 0;                       // K2p with a threshold wavefront per workgroup: 0 auto (when built for the width), 1 on, 2 off
     int opt_k2_split_max = 1024;             // ... auto: runs of up to this many replicas (a wavefront per SIMD at most)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
     int resident_waves = 0;                  // co-resident wavefronts of the anneal kernel on this device
@@ -879,6 +880,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "k2_split") && value >= 0 && value <= 2) { p->opt_k2_split = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_split_max") && value >= 0) { p->opt_k2_split_max = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_wide") && value >= 0 && value <= 2) { p->opt_k2_wide = (int)value; return MI_OK; }
+    if (!strcmp(key, "k2_tw") && value >= 0 && value <= 2) { p->opt_k2_tw = (int)value; return MI_OK; }
     if (!strcmp(key, "min_cluster_size") && value >= 0) {
         if (p->kind != MI_KIND_POTTS_CSR) return fail(MI_EINVAL, "min_cluster_size applies to Potts problems");
         p->opt_min_cluster_size = (int)value;
@@ -1040,7 +1042,7 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
                 rc = mi_launch_csr_rank1_split(a, p->k2_free_block / 64, p->stream);
             } else if (choice == 1) {
                 a.adj4 = p->d_adj4p;                  // two replicas per wavefront: half the adjacency traffic per update
-                rc = mi_launch_csr_rank1_pair(a, p->stream);
+                rc = mi_launch_csr_rank1_pair(a, p->opt_k2_tw != 2 && p->D == 16, p->stream);
             } else {
                 rc = mi_launch_csr_rank1(a, p->stream);
             }

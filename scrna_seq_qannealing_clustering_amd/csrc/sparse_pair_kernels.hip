@@ -20,11 +20,26 @@ namespace {
 
 typedef _Float16 half_t;
 
+// phase cycle counters of the sweeping wavefront (`make dbg DBG_FLAGS=-DMI_K2P_PROFILE DBG_NAME=pprof`; perturbs the run)
+#ifdef MI_K2P_PROFILE
+#define K2P_TICK(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); var += now_ - tick_; tick_ = now_; } while (0)
+#else
+#define K2P_TICK(var) do { } while (0)
+#endif
+
 __device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_bit_cast(half_t, (uint16_t)w); }
 __device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(half_t, (uint16_t)(w >> 16)); }
 
-template <int D>
-__global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
+// TW ("threshold wavefront", round 3): the workgroup has a SECOND wavefront that does the part of a sweep which does not
+// depend on the state -- the random words (Philox) and the thresholds -ln(u) * T of both replicas -- one group of four
+// slots ahead, and hands them over through a two-deep ring in LDS (one ds_write_b64 / ds_read_b64 per slot and lane,
+// one s_barrier per group).  Why: with two wavefronts per SIMD the kernel is bound by what ONE wavefront can issue
+// (a lone wavefront issues a vector instruction every 5.8 cycles, scripts/ubench_valu.hip; the SIMD could take one every
+// 1.5-2), and a third of the instructions of a slot are these thresholds.  A 128-thread workgroup puts its two
+// wavefronts on different SIMDs and every SIMD ends up with two sweeping and two threshold wavefronts
+// (scripts/probe_placement.hip).  Same chain: the thresholds are the same function of (variable, sweep, replica).
+template <int D, bool TW>
+__global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_pair(EllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // cell of variable i at byte 4 i
     const int lane = threadIdx.x & 63;
@@ -36,6 +51,47 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
     const int n = a.n, slots = a.slots;
     const uint8_t *init = static_cast<const uint8_t *>(a.init);
     uint32_t *cell = reinterpret_cast<uint32_t *>(lds);
+    // TW: the ring of thresholds behind the cells: 2 groups x 4 slots x 64 lanes x (thrA, thrB)
+    const uint32_t ring_lane = (((uint32_t)slots * 256u + 4095u) & ~4095u) + (uint32_t)lane * 8u;
+
+    if constexpr (TW) {
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) {
+            // ---- the threshold wavefront ----
+            uint32_t wa[4], wb[4];
+            uint32_t buf = 0;
+            for (int s = 0; s < a.num_sweeps; ++s) {
+                float TA, TB;
+                if (a.temps_per_replica) {
+                    TA = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[rA])));
+                    TB = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[liveB ? rB : rA])));
+                } else {
+                    TA = TB = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+                }
+                const uint32_t sw = (uint32_t)s + a.sweep_offset;
+#pragma unroll 1
+                for (int t = 0; t < slots; t += 4) {
+#ifdef MI_K2P_DBG_NOPROD   /* timing only: no random words */
+                    for (int c = 0; c < 4; ++c) wa[c] = wb[c] = (uint32_t)(t + c) * 0x9E3779B9u + lane * 77u;
+#else
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gidA, 0u, a.seed_lo, a.seed_hi, wa);
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gidB, 0u, a.seed_lo, a.seed_hi, wb);
+#endif
+                    const uint32_t at = ring_lane + buf;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x2_t thr = neglog_u2(wa[c], wb[c]) * f32x2_t{TA, TB};
+                        asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(at), "v"(thr), "n"(c * 512) : "memory");
+                    }
+                    buf ^= 2048u;
+                    // group (s, t) is in the ring: the sweeping wavefront passes the same barrier before it reads it, and
+                    // passes the NEXT one only after it has read it -- so the buffer written next (the other one) is free
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            return;
+        }
+    }
 
     int SA = 0, SB = 0;
     for (int tg = 0; tg * 4 < slots; ++tg) {
@@ -96,10 +152,18 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
     auto fetch_adj = [&](int) { return adj0; };
 #endif
 
+#ifdef MI_K2P_PROFILE
+    unsigned long long tick_ = __builtin_amdgcn_s_memtime(), t_top = 0, t_gather = 0, t_sum = 0, t_rounds = 0, t_barrier = 0;
+#endif
+#ifndef MI_K2P_DBG_NOPRIO
+    if constexpr (TW) __builtin_amdgcn_s_setprio(3);
+#endif               // the sweeping wavefront is the critical path of its workgroup
     unsigned long long accepted = 0;
+    uint32_t accA = 0, accB = 0;                                    // accepted moves of the running sweep, per replica
     uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     float TA = 1.0f, TB = 1.0f;
     const float cp = a.c_pair;
+    uint32_t ring_at = ring_lane;                                   // TW: this lane's thresholds of the group being swept
 
     // one slot for both replicas; `wordA` / `wordB` = this slot's random words.
     // Order of a slot: (1) the LDS reads are ISSUED -- the lane's own cell and the 16 neighbour cells; (2) while they are in
@@ -110,11 +174,14 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
     // data dependence, not a scheduling accident -- and the wait is lgkmcnt(0), so whatever LDS or scalar-memory
     // operation the compiler may place before it is waited for as well (scripts/check_asm_lds.py checks the emitted
     // code for a read of such a register ahead of its wait at build time).
-    auto slot_body = [&](int t, const SlotAdj &cur, uint32_t wordA, uint32_t wordB) {
+    auto slot_body = [&](auto c_in_group, int t, const SlotAdj &cur, uint32_t wordA, uint32_t wordB) {
+        constexpr int C = decltype(c_in_group)::value;
         const int i = t * 64 + lane;
         uint32_t own;                                               // [x_A | x_B] of this lane's variable
         float gA = __uint_as_float(cur.lin), gB = gA;               // (lanes past n carry lin = +inf: never accepted)
         float thrA = 0.0f, thrB = 0.0f;
+        f32x2_t thr2 = {0.0f, 0.0f};
+        K2P_TICK(t_top);
 #pragma unroll
         for (int g0 = 0; g0 < G; g0 += 4) {
             uint32_t word[16];
@@ -122,8 +189,21 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
             if (g0 == 0) asm volatile("ds_read_b32 %0, %1" : "=v"(own) : "v"(i * 4));
 #pragma unroll
             for (int k = 0; k < 16; ++k)
+#ifdef MI_K2P_DBG_LINEAR   /* timing only: conflict-free addresses */
+                asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"((cur.col[g0 + k / 4][k & 3] & 0x3f00u) + lane * 4));
+#else
                 asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"(cur.col[g0 + k / 4][k & 3]));
-            if (g0 == 0) {
+#endif
+            if (g0 == 0 && TW) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(thr2) : "v"(ring_at), "n"(C * 512));
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(word[4]), "+v"(word[5]),
+                               "+v"(word[6]), "+v"(word[7]), "+v"(word[8]), "+v"(word[9]), "+v"(word[10]), "+v"(word[11]),
+                               "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15]), "+v"(own), "+v"(thr2)
+                             :: "memory");
+                thrA = thr2.x;
+                thrB = thr2.y;
+            } else if (g0 == 0) {
                 asm volatile("" : "+v"(wordA), "+v"(wordB));        // (keeps the threshold arithmetic behind the reads' issue)
                 const f32x2_t thr = neglog_u2(wordA, wordB) * f32x2_t{TA, TB};
                 thrA = thr.x;
@@ -140,6 +220,7 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
                                "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15])
                              :: "memory");
             }
+            K2P_TICK(t_gather);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const float v = __uint_as_float(cur.val[g0 + k / 4][k & 3]);
@@ -158,57 +239,84 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
         f32x2_t de = gs + cs * f32x2_t{(float)ownA, (float)ownB};
         bool mA = de.x < thrA, mB = de.y < thrB;
         uint64_t AA = __ballot(mA), AB = __ballot(mB);
+        K2P_TICK(t_sum);
         if ((AA | AB) != 0ull) {                                    // wave-uniform
             const int baseA = ownA - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(XA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)XA, 0u));
             const int baseB = ownB - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(XB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)XB, 0u));
-            for (int round = 0; round < 66; ++round) {
-                const uint64_t BA = AA ^ XA, BB = AB ^ XB;
+            // (the loop ends by itself: a lane's decision depends on the masks of the lanes below it only, so after k rounds the
+            // lowest k lanes are final whatever the data -- NaNs included, a compare with one is just false -- and round 65
+            // repeats round 64.  Everything that leaves the loop is a wave-uniform mask: a per-lane flag live across it costs
+            // six scalar instructions a round, a round counter five)
+            uint64_t BA = AA ^ XA, BB = AB ^ XB;                    // the states after the moves guessed so far
+#ifndef MI_K2P_DBG_NOROUNDS   /* (timing only: the first masks stand) */
+#pragma nounroll
+            for (;;) {
                 const int sA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(BA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)BA, (uint32_t)baseA));
                 const int sB = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(BB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)BB, (uint32_t)baseB));
                 de = gs + cs * f32x2_t{(float)sA, (float)sB};
-                mA = de.x < thrA;
-                mB = de.y < thrB;
-                const uint64_t NA = __ballot(mA), NB = __ballot(mB);
-                const bool same = NA == AA && NB == AB;
-                AA = NA;
-                AB = NB;
-                if (same) break;
+                const uint64_t NBA = __ballot(de.x < thrA) ^ XA, NBB = __ballot(de.y < thrB) ^ XB;
+                uint64_t d0 = NBA ^ BA, d1 = NBB ^ BB;
+                asm("" : "+s"(d0), "+s"(d1));                       // (opaque: hipcc turns (a^b)|(c^d) == 0 into two compares and selects)
+                BA = NBA;
+                BB = NBB;
+                if ((d0 | d1) == 0ull) break;
             }
-            SA += __popcll(AA & ~XA) - __popcll(AA & XA);
-            SB += __popcll(AB & ~XB) - __popcll(AB & XB);
-            accepted += (unsigned long long)(__popcll(AA) + (liveB ? __popcll(AB) : 0));
+#endif
+            AA = BA ^ XA;
+            AB = BB ^ XB;
+            // sum(x) moves by popc(new states) - popc(old states) of the slot
+            SA += __popcll(BA) - __popcll(XA);
+            SB += __popcll(BB) - __popcll(XB);
+            accA += (uint32_t)__popcll(AA);
+            accB += (uint32_t)__popcll(AB);
             // toggling a state is one XOR of its half; every lane stores its cell (unchanged cells keep their word)
-            cell[i] = own ^ (mA ? 0x3c00u : 0u) ^ (mB ? 0x3c000000u : 0u);
+            uint32_t tA, tB;
+            asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(tA) : "v"(0x3c00u), "s"(AA));
+            asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(tB) : "v"(0x3c000000u), "s"(AB));
+            cell[i] = own ^ tA ^ tB;
         }
+        K2P_TICK(t_rounds);
     };
 
+    using std::integral_constant;
     for (int s = 0; s < a.num_sweeps; ++s) {
-        if (a.temps_per_replica) {
-            TA = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[rA])));
-            TB = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[liveB ? rB : rA])));
-        } else {
-            TA = TB = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+        if constexpr (!TW) {
+            if (a.temps_per_replica) {
+                TA = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[rA])));
+                TB = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[liveB ? rB : rA])));
+            } else {
+                TA = TB = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[s])));
+            }
         }
         const uint32_t sw = (uint32_t)s + a.sweep_offset;
         // four slots per trip (one Philox block per replica), the adjacency one slot ahead in two register sets
         SlotAdj P = fetch_adj(0), Q;
 #pragma unroll 1
         for (int t = 0; t < slots; t += 4) {
-            philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gidA, 0u, a.seed_lo, a.seed_hi, wa);
-            philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gidB, 0u, a.seed_lo, a.seed_hi, wb);
+            if constexpr (TW) {
+                K2P_TICK(t_top);
+                __builtin_amdgcn_s_barrier();                       // this group's thresholds are in the ring
+                K2P_TICK(t_barrier);
+            } else {
+                philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gidA, 0u, a.seed_lo, a.seed_hi, wa);
+                philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gidB, 0u, a.seed_lo, a.seed_hi, wb);
+            }
             Q = fetch_adj(t + 1);
-            slot_body(t, P, wa[0], wb[0]);
+            slot_body(integral_constant<int, 0>{}, t, P, wa[0], wb[0]);
             if (t + 1 < slots) {                                    // wave-uniform
                 P = fetch_adj(t + 2);
-                slot_body(t + 1, Q, wa[1], wb[1]);
+                slot_body(integral_constant<int, 1>{}, t + 1, Q, wa[1], wb[1]);
                 if (t + 2 < slots) {
                     Q = fetch_adj(t + 3);
-                    slot_body(t + 2, P, wa[2], wb[2]);
+                    slot_body(integral_constant<int, 2>{}, t + 2, P, wa[2], wb[2]);
                     P = fetch_adj(t + 4);
-                    if (t + 3 < slots) slot_body(t + 3, Q, wa[3], wb[3]);
+                    if (t + 3 < slots) slot_body(integral_constant<int, 3>{}, t + 3, Q, wa[3], wb[3]);
                 }
             }
+            if constexpr (TW) ring_at ^= 2048u;
         }
+        accepted += (unsigned long long)accA + (liveB ? (unsigned long long)accB : 0ull);
+        accA = accB = 0;
     }
 
     // ---- epilogue: states out, exact fp64 energies (same sums as k_anneal_csr_rank1) ----
@@ -242,17 +350,26 @@ __global__ void __launch_bounds__(64, 2) k_anneal_csr_rank1_pair(EllArgs a)
         }
     }
     if (lane == 0) atomicAdd(&a.stats[1], accepted);
+#ifdef MI_K2P_PROFILE
+    if (lane == 0) {
+        atomicAdd(&a.stats[8], t_top); atomicAdd(&a.stats[9], t_gather); atomicAdd(&a.stats[10], t_sum);
+        atomicAdd(&a.stats[11], t_rounds); atomicAdd(&a.stats[12], t_barrier);
+    }
+#endif
 }
 
 template <typename KernelT>
-int launch_pair(KernelT kernel, const EllArgs &a, hipStream_t st)
+int launch_pair(KernelT kernel, const EllArgs &a, bool tw, hipStream_t st)
 {
-    const size_t lds = (size_t)a.slots * 256;                      // 4 bytes per variable
+    // 4 bytes per variable; TW: the ring of thresholds behind them (its two halves are told apart by address bit 11:
+    // the cells end on a multiple of 256 bytes, so the ring starts on a multiple of 4096 behind some padding)
+    size_t lds = (size_t)a.slots * 256;
+    if (tw) lds = ((lds + 4095) / 4096) * 4096 + 4096;
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1 pair kernel: n = %d exceeds the state LDS budget", a.n);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    note_kernel("k_anneal_csr_rank1_pair<%d>", a.D);
-    hipLaunchKernelGGL(kernel, dim3((a.R + 1) / 2), dim3(64), lds, st, a);
+    note_kernel(tw ? "k_anneal_csr_rank1_pair<%d, tw>" : "k_anneal_csr_rank1_pair<%d>", a.D);
+    hipLaunchKernelGGL(kernel, dim3((a.R + 1) / 2), dim3(tw ? 128 : 64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -260,11 +377,12 @@ int launch_pair(KernelT kernel, const EllArgs &a, hipStream_t st)
 }  // namespace
 
 // a.adj4 must hold the pair packing (neighbour word = 4 * index)
-int mi_launch_csr_rank1_pair(const EllArgs &a, hipStream_t st)
+int mi_launch_csr_rank1_pair(const EllArgs &a, bool tw, hipStream_t st)
 {
     if (!a.adj4) return fail(MI_EHIP, "csr_rank1 pair kernel: packed adjacency missing");
-    if (a.D == 16) return launch_pair(k_anneal_csr_rank1_pair<16>, a, st);
-    if (a.D == 32) return launch_pair(k_anneal_csr_rank1_pair<32>, a, st);
+    if (a.D == 16 && tw) return launch_pair(k_anneal_csr_rank1_pair<16, true>, a, true, st);
+    if (a.D == 16) return launch_pair(k_anneal_csr_rank1_pair<16, false>, a, false, st);
+    if (a.D == 32) return launch_pair(k_anneal_csr_rank1_pair<32, false>, a, false, st);
     return fail(MI_EUNSUPPORTED, "csr_rank1 pair kernel: slot-ELL width %d not built", a.D);
 }
 
