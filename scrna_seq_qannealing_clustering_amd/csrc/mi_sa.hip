@@ -1033,10 +1033,14 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
             else if (p->opt_k2_pair == 1 && pair_ok) choice = 1;
             else if (p->opt_k2_split != 2 && split_ok && R <= p->opt_k2_split_max) choice = 2;
             else if (p->opt_k2_pair != 2 && pair_ok && R > 1024) choice = 1;
+            const bool tw = p->opt_k2_tw != 2;         // a threshold wavefront beside the sweeping one (same chain)
             if (choice == 2 && p->k2_free_block > 64 && p->opt_k2_wide != 2 && (p->D == 16 || p->k2_free_block == 128)) {
                 // blocks of 128 / 256 edge-free seats, few replicas: ONE wavefront sweeps a block per step
                 a.adj4 = p->d_adj4p;
-                rc = mi_launch_csr_rank1_wide(a, p->k2_free_block / 64, p->stream);
+                rc = mi_launch_csr_rank1_wide(a, p->k2_free_block / 64, tw, p->stream);
+            } else if (choice == 2 && p->k2_free_block == 64 && p->opt_k2_wide != 2 && tw) {
+                a.adj4 = p->d_adj4p;                  // 64-seat layouts: one slot per step, thresholds from the second wavefront
+                rc = mi_launch_csr_rank1_wide(a, 1, true, p->stream);
             } else if (choice == 2) {
                 a.adj4 = p->d_adj4p;
                 rc = mi_launch_csr_rank1_split(a, p->k2_free_block / 64, p->stream);

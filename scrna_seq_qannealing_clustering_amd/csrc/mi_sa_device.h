@@ -297,7 +297,7 @@ struct EllArgs {
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_csr_rank1_pair(const EllArgs &, bool tw, hipStream_t);   // sparse_pair_kernels.hip: two replicas per wavefront (tw: + a threshold wavefront)
 int mi_launch_csr_rank1_split(const EllArgs &, int nw, hipStream_t);   // sparse_split_kernels.hip: nw wavefronts per replica
-int mi_launch_csr_rank1_wide(const EllArgs &, int spb, hipStream_t);   // ... one wavefront per replica, spb slots per step
+int mi_launch_csr_rank1_wide(const EllArgs &, int spb, bool tw, hipStream_t);   // ... one wavefront per replica, spb slots per step (tw: + a threshold wavefront; spb = 1 only so)
 int mi_launch_potts(const EllArgs &, hipStream_t);
 
 // K1x (dense_xl_kernels.hip): dense chain for 4096 < n <= 65536, one workgroup per replica

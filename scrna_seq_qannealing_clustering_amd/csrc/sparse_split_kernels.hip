@@ -400,16 +400,60 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
 // mostly WAITING (115 instructions in 950 cycles: LDS round trip, the 16-deep fma chain, vector -> scalar -> vector
 // hops); two or four slots' worth of independent work per step fill those gaps, with no exchange between wavefronts.
 // Same chain as every other kernel of the family on the same padded model, bit for bit.
-template <int D, int SPB>
-__global__ void __launch_bounds__(64, 1) k_anneal_csr_rank1_wide(EllArgs a)
+// TW (round 3): a second wavefront in the workgroup -- on another SIMD, and with few replicas the chip has SIMDs to spare --
+// computes the random words and the thresholds -ln(u) * T one group of four slots ahead and hands them over through a
+// two-deep ring in LDS, one s_barrier per group (k_anneal_csr_rank1_pair has the same arrangement): a third of the
+// instructions of a step leave the wavefront whose issue rate bounds the run.  SPB = 1 (TW only): the plain
+// one-slot-per-step sweep, for the 64-seat layouts of small or strongly clustered models.
+template <int D, int SPB, bool TW>
+__global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllArgs a)
 {
-    static_assert(SPB == 2 || SPB == 4, "two or four slots per step");
+    static_assert(SPB == 2 || SPB == 4 || (SPB == 1 && TW), "one (with a threshold wavefront), two or four slots per step");
     extern __shared__ __attribute__((aligned(16))) char lds[];      // one 32-bit cell per seat, low half = x (0.0 / 1.0)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x;
     const uint32_t gid = a.replica_offset + (uint32_t)r;
     const int n = a.n, slots = a.slots, blocks = slots / SPB;       // slots is a multiple of SPB (launcher)
     const uint8_t *init = static_cast<const uint8_t *>(a.init);
+    // TW: the ring behind the cells, two groups of [4 / SPB steps][64 lanes][SPB thresholds] (1 KB each)
+    const uint32_t ring_lane = (uint32_t)slots * 256u + (uint32_t)lane * (4u * SPB);
+
+    if constexpr (TW) {
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) {
+            // ---- the threshold wavefront ----
+            uint32_t w[4];
+            uint32_t buf = 0;
+            for (int s = 0; s < a.num_sweeps; ++s) {
+                const float T = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[a.temps_per_replica ? r : s])));
+                const uint32_t sw = (uint32_t)s + a.sweep_offset;
+#pragma unroll 1
+                for (int t = 0; t < slots; t += 4) {
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gid, 0u, a.seed_lo, a.seed_hi, w);
+                    const f32x2_t l01 = neglog_u2(w[0], w[1]) * f32x2_t{T, T}, l23 = neglog_u2(w[2], w[3]) * f32x2_t{T, T};
+                    const uint32_t at = ring_lane + buf;
+                    if constexpr (SPB == 4) {
+                        const f32x4 v = {l01.x, l01.y, l23.x, l23.y};
+                        asm volatile("ds_write_b128 %0, %1" :: "v"(at), "v"(v) : "memory");
+                    } else if constexpr (SPB == 2) {
+                        asm volatile("ds_write_b64 %0, %1" :: "v"(at), "v"(l01) : "memory");
+                        asm volatile("ds_write_b64 %0, %1 offset:512" :: "v"(at), "v"(l23) : "memory");
+                    } else {
+                        asm volatile("ds_write_b32 %0, %1" :: "v"(at), "v"(l01.x) : "memory");
+                        asm volatile("ds_write_b32 %0, %1 offset:256" :: "v"(at), "v"(l01.y) : "memory");
+                        asm volatile("ds_write_b32 %0, %1 offset:512" :: "v"(at), "v"(l23.x) : "memory");
+                        asm volatile("ds_write_b32 %0, %1 offset:768" :: "v"(at), "v"(l23.y) : "memory");
+                    }
+                    buf ^= 1024u;
+                    // the sweeping wavefront passes this barrier before it reads the group and the next one only after it
+                    // has read it: the buffer written next (the other one) is free by then
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            return;
+        }
+        __builtin_amdgcn_s_setprio(3);
+    }
 
     int S = 0;
     for (int t = 0; t < slots; ++t) {
@@ -454,6 +498,7 @@ __global__ void __launch_bounds__(64, 1) k_anneal_csr_rank1_wide(EllArgs a)
     };
 
     unsigned long long accepted = 0;
+    uint32_t acc32 = 0;                                             // accepted moves of the running sweep
     float T = 1.0f;
     const float cp = a.c_pair;
     uint32_t sw = a.sweep_offset;
@@ -464,9 +509,15 @@ __global__ void __launch_bounds__(64, 1) k_anneal_csr_rank1_wide(EllArgs a)
     int cur_g = -1;
     nx.start((uint32_t)lane, sw, gid, 0u, a.seed_lo, a.seed_hi);
 
+    uint32_t ring_buf = 1024u;                                      // TW: which half of the ring the running group is in (toggled at its start)
     auto step = [&](int b, const BlockAdj &cur) {
         const int t0 = b * SPB;
-        if ((t0 >> 2) != cur_g) {                                   // wave-uniform: this block opens a new group of four slots
+        if constexpr (TW) {
+            if ((t0 & 3) == 0) {                                    // wave-uniform: this block opens a new group of four slots
+                __builtin_amdgcn_s_barrier();                       // ... whose thresholds are in the ring
+                ring_buf ^= 1024u;
+            }
+        } else if ((t0 >> 2) != cur_g) {
             while (nx.done < 10) nx.round();
             cw[0] = nx.c0; cw[1] = nx.c1; cw[2] = nx.c2; cw[3] = nx.c3;
             cur_g = t0 >> 2;
@@ -483,23 +534,38 @@ __global__ void __launch_bounds__(64, 1) k_anneal_csr_rank1_wide(EllArgs a)
             for (int k = 0; k < 16; ++k)
                 asm volatile("ds_read_b32 %0, %1" : "=v"(word[j][k]) : "v"(cur.s[j].col[k / 4][k & 3]));
         }
-        // (2) behind their issue: the SPB thresholds (pairs of them as packed arithmetic) and a share of the next random words
-        uint32_t rw[SPB];
-#pragma unroll
-        for (int j = 0; j < SPB; ++j) {
-            const int c = (t0 + j) & 3;                             // (SPB = 4: c = j; SPB = 2: 0, 1 or 2, 3)
-            rw[j] = c == 0 ? cw[0] : (c == 1 ? cw[1] : (c == 2 ? cw[2] : cw[3]));
-        }
-        asm volatile("" : "+v"(rw[0]), "+v"(rw[1]), "+v"(nx.c0), "+v"(nx.c1), "+v"(nx.c2), "+v"(nx.c3));
         float thr[SPB];
+        typedef float thr_vec_t __attribute__((ext_vector_type(SPB == 1 ? 2 : SPB)));
+        thr_vec_t tv;                                               // TW: the step's thresholds as they come from the ring
+        if constexpr (TW) {
+            // (2) the SPB thresholds of the step from the ring: one read, waited for with the gathers (below)
+            const uint32_t at = ring_lane + ring_buf + (uint32_t)(t0 & 3) * 256u;
+            if constexpr (SPB == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(tv) : "v"(at));
+            else if constexpr (SPB == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(tv) : "v"(at));
+            else asm volatile("ds_read_b32 %0, %1" : "=v"(tv.x) : "v"(at));
+        } else {
+            // (2) behind their issue: the SPB thresholds (pairs of them as packed arithmetic) and a share of the next random words
+            uint32_t rw[SPB];
 #pragma unroll
-        for (int j = 0; j < SPB; j += 2) {
-            const f32x2_t l2 = neglog_u2(rw[j], rw[j + 1]) * f32x2_t{T, T};
-            thr[j] = l2.x;
-            thr[j + 1] = l2.y;
+            for (int j = 0; j < SPB; ++j) {
+                const int c = (t0 + j) & 3;                         // (SPB = 4: c = j; SPB = 2: 0, 1 or 2, 3)
+                rw[j] = c == 0 ? cw[0] : (c == 1 ? cw[1] : (c == 2 ? cw[2] : cw[3]));
+            }
+            asm volatile("" : "+v"(rw[0]), "+v"(rw[SPB - 1]), "+v"(nx.c0), "+v"(nx.c1), "+v"(nx.c2), "+v"(nx.c3));
+#pragma unroll
+            for (int j = 0; j + 1 < SPB; j += 2) {
+                const f32x2_t l2 = neglog_u2(rw[j], rw[j + 1]) * f32x2_t{T, T};
+                thr[j] = l2.x;
+                thr[j + 1] = l2.y;
+            }
+#pragma unroll
+            for (int k = 0; k < (10 * SPB) / 4; ++k) nx.round();    // (a group lasts 4 / SPB steps: never past ten rounds)
         }
+        if constexpr (TW) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv) :: "memory");
 #pragma unroll
-        for (int k = 0; k < (10 * SPB) / 4; ++k) nx.round();        // (a group lasts 4 / SPB steps: never past ten rounds)
+            for (int j = 0; j < SPB; ++j) thr[j] = tv[j];
+        }
         // (3) the field sums: SPB independent chains
         float gi[SPB];
 #pragma unroll
@@ -542,20 +608,28 @@ __global__ void __launch_bounds__(64, 1) k_anneal_csr_rank1_wide(EllArgs a)
             const uint32_t sgnbit = xi << 31;                       // dE = x ? -f : f
             const float gs = __uint_as_float(__float_as_uint(gi[j]) ^ sgnbit);
             const float cs = __uint_as_float(__float_as_uint(cp) ^ sgnbit);
-            uint64_t A = __ballot(gs + cs * (float)(S - (int)xi) < thr[j]);
-            if (A != 0ull) {                                        // wave-uniform
+            const uint64_t A0 = __ballot(gs + cs * (float)(S - (int)xi) < thr[j]);
+            if (A0 != 0ull) {                                       // wave-uniform
                 const int base = S - (int)xi - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(X >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)X, 0u));
-                for (int round = 0; round < 66; ++round) {
-                    const uint64_t Bm = A ^ X;
+                // rounds until the states after the moves reproduce themselves (ends by itself: after k rounds the lowest
+                // k lanes are final); only wave-uniform masks live across the loop
+                uint64_t Bm = A0 ^ X;
+#pragma nounroll
+                for (;;) {
                     const int s_i = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(Bm >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)Bm, (uint32_t)base));
-                    const uint64_t A2 = __ballot(gs + cs * (float)s_i < thr[j]);
-                    if (A2 == A) break;
-                    A = A2;
+                    const uint64_t B2 = __ballot(gs + cs * (float)s_i < thr[j]) ^ X;
+                    uint64_t d = B2 ^ Bm;
+                    asm("" : "+s"(d));
+                    Bm = B2;
+                    if (d == 0ull) break;
                 }
-                if ((A >> lane) & 1ull) asm volatile("ds_write_b32 %0, %1" :: "v"(i * 4), "v"(own[j] ^ 0x3c00u) : "memory");
-                S += __popcll(A & ~X) - __popcll(A & X);
-                accepted += (unsigned long long)__popcll(A);
+                const uint64_t A = Bm ^ X;
+                uint32_t tgl;
+                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(tgl) : "v"(0x3c00u), "s"(A));
+                asm volatile("ds_write_b32 %0, %1" :: "v"(i * 4), "v"(own[j] ^ tgl) : "memory");
+                S += __popcll(Bm) - __popcll(X);
+                acc32 += (uint32_t)__popcll(A);
             }
         }
     };
@@ -574,6 +648,8 @@ __global__ void __launch_bounds__(64, 1) k_anneal_csr_rank1_wide(EllArgs a)
                 step(b + 1, Q);
             }
         }
+        accepted += acc32;
+        acc32 = 0;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -606,15 +682,15 @@ __global__ void __launch_bounds__(64, 1) k_anneal_csr_rank1_wide(EllArgs a)
 }
 
 template <typename KernelT>
-int launch_wide(KernelT kernel, const EllArgs &a, int spb, hipStream_t st)
+int launch_wide(KernelT kernel, const EllArgs &a, int spb, bool tw, hipStream_t st)
 {
-    const size_t lds = (size_t)a.slots * 256;
+    const size_t lds = (size_t)a.slots * 256 + (tw ? 2048 : 0);    // the cells; tw: + the ring of thresholds
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1 wide kernel: n = %d exceeds the state LDS budget", a.n);
     if (a.slots % spb != 0) return fail(MI_EINVAL, "csr_rank1 wide kernel: %d slots are not whole blocks of %d", a.slots, spb);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    note_kernel("k_anneal_csr_rank1_wide<%d, %d>", a.D, spb);
-    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(64), lds, st, a);
+    note_kernel(tw ? "k_anneal_csr_rank1_wide<%d, %d, tw>" : "k_anneal_csr_rank1_wide<%d, %d>", a.D, spb);
+    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(tw ? 128 : 64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -639,13 +715,21 @@ int launch_split(KernelT kernel, const EllArgs &a, int nw, hipStream_t st)
 
 // one wavefront per replica, spb = 2 / 4 slots per step (a model whose every block of 64 * spb seats is free of internal
 // edges; a.adj4 = the pair kernel's packing)
-int mi_launch_csr_rank1_wide(const EllArgs &a, int spb, hipStream_t st)
+int mi_launch_csr_rank1_wide(const EllArgs &a, int spb, bool tw, hipStream_t st)
 {
     if (!a.adj4) return fail(MI_EHIP, "csr_rank1 wide kernel: packed adjacency missing");
-    if (a.D == 16 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<16, 2>, a, spb, st);
-    if (a.D == 16 && spb == 4) return launch_wide(k_anneal_csr_rank1_wide<16, 4>, a, spb, st);
-    if (a.D == 32 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<32, 2>, a, spb, st);
-    return fail(MI_EUNSUPPORTED, "csr_rank1 wide kernel: width %d / %d slots per step not built", a.D, spb);
+    if (tw) {
+        if (a.D == 16 && spb == 1) return launch_wide(k_anneal_csr_rank1_wide<16, 1, true>, a, spb, true, st);
+        if (a.D == 16 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<16, 2, true>, a, spb, true, st);
+        if (a.D == 16 && spb == 4) return launch_wide(k_anneal_csr_rank1_wide<16, 4, true>, a, spb, true, st);
+        if (a.D == 32 && spb == 1) return launch_wide(k_anneal_csr_rank1_wide<32, 1, true>, a, spb, true, st);
+        if (a.D == 32 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<32, 2, true>, a, spb, true, st);
+    } else {
+        if (a.D == 16 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<16, 2, false>, a, spb, false, st);
+        if (a.D == 16 && spb == 4) return launch_wide(k_anneal_csr_rank1_wide<16, 4, false>, a, spb, false, st);
+        if (a.D == 32 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<32, 2, false>, a, spb, false, st);
+    }
+    return fail(MI_EUNSUPPORTED, "csr_rank1 wide kernel: width %d / %d slots per step%s not built", a.D, spb, tw ? " with a threshold wavefront" : "");
 }
 
 // a.adj4 must hold the pair kernel's packing (neighbour word = 4 * index) of a model whose every block of 64 * nw seats

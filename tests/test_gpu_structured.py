@@ -195,11 +195,12 @@ def test_csr_rank1_padded_layout_of_a_clustered_subgraph():
     with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), c_pair, order="padded",
                            energy_model=(m.val, m.lin, m.c_pair)) as p:
         assert p.n == n and p.n_dev == N
-        for mode in (2, 1):
+        for mode, tw in ((2, 0), (1, 2), (1, 1)):         # a few-replica kernel; K2p alone; K2p with its threshold wavefront
             p.set_option("k2_pair", mode)
+            p.set_option("k2_tw", tw)
             p.anneal(9, betas, 8, replica_offset=3)
             st, en, info = p.fetch()
-            assert ("pair" in p.kernel_name()) == (mode == 1)
+            assert ("pair" in p.kernel_name()) == (mode == 1) and (mode != 1 or ("tw>" in p.kernel_name()) == (tw == 1))
             assert st.shape == (9, n) and np.array_equal(st, o_rand[0][:, pos])
             assert info["accepted"] == int(o_rand[2][1]) and info["proposals"] == 9 * 30 * n == int(o_rand[2][0])
             assert np.allclose(en, m.energies(st), rtol=1e-12)
@@ -259,10 +260,20 @@ def test_few_replica_kernel_workgroup_per_replica(case):
         assert p.n == n and p.n_dev == N
         p.anneal(R, betas, 8, replica_offset=3)
         name = p.kernel_name()
-        # few replicas: blocks of 64 -> K2s with one wavefront; wider blocks -> K2w, ONE wavefront sweeping 2 / 4 slots per step
-        assert name.startswith("k_anneal_csr_rank1_split<" if block == 64 else "k_anneal_csr_rank1_wide<"), name
-        assert name.endswith(", %d>" % (block // 64)), name
+        # few replicas: ONE wavefront sweeps a block of 64 / 128 / 256 seats per step (K2w: 1 / 2 / 4 slots), a second
+        # wavefront of its workgroup computes the thresholds ahead of it ...
+        wide_built = block <= 128 or "wide" not in case                          # (32 entries per variable: up to two slots per step)
+        assert name == ("k_anneal_csr_rank1_wide<%d, %d, tw>" % (32 if "wide" in case else 16, block // 64) if wide_built
+                        else "k_anneal_csr_rank1_split<32, 4>"), name
         st, en, info = p.fetch()
+        p.set_option("k2_tw", 2)                       # ... or the sweeping wavefront does (round-3 forms: K2s with one wavefront, K2w)
+        p.anneal(R, betas, 8, replica_offset=3)
+        name = p.kernel_name()
+        assert name.startswith("k_anneal_csr_rank1_split<" if block == 64 else "k_anneal_csr_rank1_wide<") and "tw" not in name, name
+        assert name.endswith(", %d>" % (block // 64)), name
+        sn_, en_, in_ = p.fetch()
+        assert np.array_equal(sn_, st) and np.allclose(en_, en, rtol=1e-13) and in_["accepted"] == info["accepted"]
+        p.set_option("k2_tw", 0)
         if block > 64:                                 # ... and on request K2s with 2 / 4 wavefronts per replica: the same run
             p.set_option("k2_wide", 2)
             p.anneal(R, betas, 8, replica_offset=3)
@@ -307,7 +318,7 @@ def test_few_replica_kernel_workgroup_per_replica(case):
 def test_few_replica_kernels_random_models(seed):
     """Random sparse models (size, degree, weights, schedule, replica count and offset drawn per seed) laid out in
     edge-free blocks of 64 / 128 / 256 seats and run on the few-replica kernels -- K2s with 1, 2 or 4 wavefronts per
-    replica, K2w with 2 or 4 slots per step -- against the oracle on the same padded model: states, accepted counts,
+    replica, K2w with 1, 2 or 4 slots per step, with and without its threshold wavefront -- against the oracle on the same padded model: states, accepted counts,
     energies; random initial states from the replica's own stream and given ones."""
     rs = np.random.RandomState(5000 + seed)
     n = int(rs.choice([70, 130, 257, 700, 1300]))
@@ -349,14 +360,17 @@ def test_few_replica_kernels_random_models(seed):
     o_rand = so.sa_csr_rank1_philox(rp, cc, vv, lpad, c_pair, R, betas, 7 + seed, replica_offset=off)
     o_init = so.sa_csr_rank1_philox(rp, cc, vv, lpad, c_pair, R, betas, 7 + seed, replica_offset=off, init=init_dev)
     with Problem.csr_rank1(rowptr, col, val, lin, c_pair, order="padded", block=block) as p:
-        for wide in ((0, 2) if block > 64 else (0,)):
+        for wide, tw in (((0, 0), (0, 2), (2, 0)) if block > 64 else ((0, 0), (0, 2))):
             p.set_option("k2_split", 1)
             p.set_option("k2_wide", wide)
+            p.set_option("k2_tw", tw)
             p.anneal(R, betas, 7 + seed, replica_offset=off)
             name = p.kernel_name()
-            # K2w exists with two slots per step at either width and with four at 16 entries per variable
-            is_wide = block > 64 and wide == 0 and (int(deg.max()) <= 16 or block == 128)
+            # K2w exists with two slots per step at either width and with four at 16 entries per variable; with one slot
+            # per step only beside a threshold wavefront (without one, 64-seat layouts run on K2s' one-wavefront form)
+            is_wide = wide == 0 and (block == 64 and tw == 0 or block > 64 and (int(deg.max()) <= 16 or block == 128))
             assert ("wide<" in name) == is_wide and ("split<" in name) == (not is_wide), name
+            assert ("tw>" in name) == (is_wide and tw == 0), name
             st, en, info = p.fetch()
             assert np.array_equal(st, o_rand[0][:, pos]) and info["accepted"] == int(o_rand[2][1])
             assert np.allclose(en, o_rand[1], rtol=1e-9, atol=1e-9)
