@@ -547,12 +547,13 @@ def main():
                              "(%d x 64 x 8 B) + linear terms (256 B), once per wavefront (two replicas per wavefront in the "
                              "pair kernel), every slot of every sweep; peak = L2 aggregate (MI355X_MICROARCH.md)" % ell_width,
                     "binding_resource": binding_resource(kernel_name, R, len(betas)),
-                    "what_binds": "NOT this path: a timing-only build of the kernel without any adjacency traffic takes the same "
-                                  "time (profiles/r03_k2p_without_adjacency_traffic.txt), and 12 % fewer vector instructions "
-                                  "bought 2 % (profiles/r03_k2_binding.json against r02): the dependent chain of a 64-variable "
-                                  "slot (state write -> LDS gathers -> 16-deep fma chain -> compare -> ballot -> rounds) with two "
-                                  "wavefronts per SIMD -- 4096 replicas are four per SIMD however they are packed; three "
-                                  "wavefronts per SIMD (6144 replicas) give +14 % (DESIGN.md section 5)"}
+                    "what_binds": "this path, nearly: with the thresholds computed by a second wavefront per workgroup (round 3) the "
+                                  "sweeping wavefronts of a CU fetch 8 x 8.25 KB of adjacency per slot, ~57 B/clk of the 64 B/clk a CU's "
+                                  "vector-memory path delivers at the clock the chip holds under this load (1.97 GHz in the counter passes); "
+                                  "a timing-only build without adjacency traffic runs 25.2 -> 21.3 ms, without the threshold wavefront's "
+                                  "arithmetic 24.0, without accept rounds 24.9, with conflict-free LDS gathers 25.7 "
+                                  "(profiles/r03_d_k2p_tw_timing_experiments.txt); LDS 74 % busy, wavefronts issuing 35 % / waiting for an "
+                                  "issue slot 25 % / parked on s_waitcnt 40 % of their cycles (profiles/r03_k2_binding.json)"}
     roofline.update({"kernel": kernel_name, "kernel_ms": launch_ms, "launches_per_step": launches,
                      "sweeps_per_launch": sweeps_per_launch, "kernel_ms_per_step": k_ms, "acceptance": accept})
     best_state = best[3]

@@ -22,6 +22,7 @@ for f in sorted(glob.glob(os.path.join(d, "p*.csv"))):
         kernel = r["Kernel_Name"]
         dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
 name = re.search(r"(k_\w+<[^>]*>)", kernel).group(1)
+name = name.replace(", true>", ", tw>").replace(", false>", ">")      # (the name the library reports: mi_sa_last_kernel_name)
 cycles = vals["GRBM_GUI_ACTIVE"] / 8.0
 ms = sorted(dur)[len(dur) // 2]
 l2_bytes = vals["TCC_REQ_sum"] * 128.0
