@@ -411,8 +411,8 @@ int orc_csr_rank1_fp32_vs_fp64_decisions(const int *rowptr, const int *col, cons
  * State l_i in [0,K).  Proposal for variable i at sweep s: target label
  *     b = (a + 1 + (word(i,s,g,2) mod (K-1))) mod K      (uniform over the K-1 other labels)
  * dE = [h_i(b) + c*cnt_b] - [h_i(a) + c*(cnt_a - 1)],  h_i(q) = sum_{j in N(i), l_j == q} S_ij
- * accepted iff dE < neglog_u(word(i,s,g,0)) * temps[s].  h is recomputed per proposal from the CSR
- * row in stored order (fp32 adds in that order); cnt are integers. */
+ * accepted iff dE < neglog_u(word(i,s,g,0)) * temps[s].  h_i(b) - h_i(a) is recomputed per proposal from the
+ * CSR row as one signed sum in stored order (fp32 adds / subtracts in that order); cnt are integers. */
 /* min_size > 0 restricts the chain to labelings in which every cluster keeps at least min_size members
  * (the "cluster_size >= 20" constraints of CQM_clustering.py:46-48 as a hard constraint): a move out of a
  * cluster that holds exactly min_size variables is rejected whatever its dE.  The restricted chain still
@@ -448,16 +448,20 @@ int orc_potts_csr_philox_absent(const int *rowptr, const int *col, const float *
                 if (absent && absent[i]) continue;
                 int a = l[i];
                 int b = (a + 1 + (int)(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 2) % (uint32_t)(K - 1))) % K;
-                float ha = 0.0f, hb = 0.0f;
+                /* field difference h_i(b) - h_i(a) as ONE signed fp32 sum in stored order: + S_ij for a neighbour
+                 * with the target label, - S_ij for one with the variable's own label (round 3; the difference of
+                 * two separate sums before: the same number up to rounding, one table lookup and one fma per
+                 * neighbour on the device, csrc/potts_fast_kernels.hip) */
+                float hd = 0.0f;
                 for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
                     int lj = l[col[e]];
-                    if (lj == a) ha = ha + val[e];
-                    if (lj == b) hb = hb + val[e];
+                    if (lj == b) hd = hd + val[e];
+                    else if (lj == a) hd = hd - val[e];
                 }
                 /* dE = (h_b + c cnt_b) - (h_a + c (cnt_a - 1)), evaluated as ONE fused multiply-add of the
                  * (exact, integer) size difference onto the (fp32) field difference -- chain specification
                  * 2c in DESIGN.md section 3; the device kernel evaluates the same expression */
-                float dE = fmaf(c_pair, (float)(cnt[b] - (cnt[a] - 1)), hb - ha);
+                float dE = fmaf(c_pair, (float)(cnt[b] - (cnt[a] - 1)), hd);
                 float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
                 ++tot_prop;
                 if (dE < thr && cnt[a] - 1 >= min_size) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build-time guard for the LDS reads the anneal kernels issue from inline asm (csrc/sparse_kernels.hip,
-sparse_pair_kernels.hip, sparse_split_kernels.hip).
+sparse_pair_kernels.hip, sparse_split_kernels.hip, potts_fast_kernels.hip).
 
 hipcc's s_waitcnt pass does not count instructions inside inline asm, so those kernels wait for their own reads with an
 asm `s_waitcnt lgkmcnt(N)` and pass every destination register THROUGH that statement ("+v"): "used only after the wait"
@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "scrna_seq_qannealing_clustering_amd", "csrc")
-FILES = ["sparse_kernels.hip", "sparse_pair_kernels.hip", "sparse_split_kernels.hip"]
+FILES = ["sparse_kernels.hip", "sparse_pair_kernels.hip", "sparse_split_kernels.hip", "potts_fast_kernels.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950",
          "--offload-device-only", "-S"]
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")

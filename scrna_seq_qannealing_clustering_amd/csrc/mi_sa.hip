@@ -214,6 +214,7 @@ struct mi_sa_problem {
     int opt_k2_pair = 0;                     // K2p: 0 auto (runs of more replicas than the chip has SIMDs), 1 always when eligible, 2 never
     int opt_k2_split = 0;                    // K2s (csrc/sparse_split_kernels.hip): 0 auto (few replicas: its one-wavefront form), 1 always when eligible (2 / 4 wavefronts per replica on models laid out in blocks of 128 / 256 seats), 2 never
     int opt_k2_wide = 0;                     // models laid out in blocks of 128 / 256 seats, few replicas: 0 / 1 one wavefront sweeps a block per step (K2w), 2 a workgroup of 2 / 4 wavefronts does (K2s)
+    int opt_k3_fast = 0;                     // K3f (csrc/potts_fast_kernels.hip): 0 auto (when the model is eligible), 2 never
     int opt_k2_tw = 0;                       // K2p with a threshold wavefront per workgroup: 0 auto (when built for the width), 1 on, 2 off
     int opt_k2_split_max = 1024;             // ... auto: runs of up to this many replicas (a wavefront per SIMD at most)
     int opt_unit_rows = 0;                   // K1w ring unit (rows per rendezvous): 0 auto, 2 or 4
@@ -479,6 +480,25 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
         HIP_TRY(hipMemcpy(p->d_rows, hr.data(), hr.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_meta, hm.data(), hm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         p->h_meta = hm;
+        if (p->kind == MI_KIND_POTTS_CSR && (D == 16 || D == 32) && (size_t)slots * 128 + 256 <= 160 * 1024) {
+            // K3f's register image of a slot (csrc/potts_fast_kernels.hip), for models whose every slot is free of internal
+            // edges: groups of four (neighbour, value) per lane, the neighbour as the LDS byte address of its 16-bit label cell
+            bool any_in_slot = false;
+            for (size_t i = 0; i < hm.size(); ++i) any_in_slot = any_in_slot || (hm[i] & 0xffu) != 0u;
+            if (!any_in_slot) {
+                const int G = D / 4;
+                std::vector<uint32_t> ha((size_t)slots * G * 2 * 64 * 4, 0u);
+                for (int t = 0; t < slots; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int k = 0; k < D; ++k) {
+                            const size_t base = (((size_t)t * G + k / 4) * 2) * 256 + (size_t)lane * 4 + (k & 3);
+                            ha[base] = 2u * hc[((size_t)t * D + k) * 64 + lane];
+                            memcpy(&ha[base + 256], &hv[((size_t)t * D + k) * 64 + lane], 4);
+                        }
+                HIP_TRY(hipMalloc((void **)&p->d_adj4p, ha.size() * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpy(p->d_adj4p, ha.data(), ha.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+        }
         if (p->kind == MI_KIND_CSR_RANK1) {
             // K2's register image of a slot: groups of four (neighbour, value) per lane, the neighbour already
             // translated into where its state bit lives in LDS (the state masks start at LDS address 0)
@@ -881,6 +901,7 @@ int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
     if (!strcmp(key, "k2_split_max") && value >= 0) { p->opt_k2_split_max = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_wide") && value >= 0 && value <= 2) { p->opt_k2_wide = (int)value; return MI_OK; }
     if (!strcmp(key, "k2_tw") && value >= 0 && value <= 2) { p->opt_k2_tw = (int)value; return MI_OK; }
+    if (!strcmp(key, "k3_fast") && value >= 0 && value <= 2) { p->opt_k3_fast = (int)value; return MI_OK; }
     if (!strcmp(key, "min_cluster_size") && value >= 0) {
         if (p->kind != MI_KIND_POTTS_CSR) return fail(MI_EINVAL, "min_cluster_size applies to Potts problems");
         p->opt_min_cluster_size = (int)value;
@@ -1021,7 +1042,12 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         p->last_launches = 1;
         HIP_TRY(hipEventRecord(p->ev0, p->stream));
         if (p->kind == MI_KIND_POTTS_CSR) {
-            rc = mi_launch_potts(a, p->stream);
+            if (p->d_adj4p && p->opt_k3_fast != 2 && mi_potts_fast_eligible(p->D, p->K, a.min_size)) {
+                a.adj4 = p->d_adj4p;                  // every slot free of internal edges: the lean kernel (same chain)
+                rc = mi_launch_potts_fast(a, p->stream);
+            } else {
+                rc = mi_launch_potts(a, p->stream);
+            }
         } else {
             // which of the kernels of the structured binary model (all run the same chain): an explicit option first;
             // otherwise few replicas -> K2s in its one-wavefront form (random words a few rounds per step, 32-bit state

@@ -299,6 +299,10 @@ int mi_launch_csr_rank1_pair(const EllArgs &, bool tw, hipStream_t);   // sparse
 int mi_launch_csr_rank1_split(const EllArgs &, int nw, hipStream_t);   // sparse_split_kernels.hip: nw wavefronts per replica
 int mi_launch_csr_rank1_wide(const EllArgs &, int spb, bool tw, hipStream_t);   // ... one wavefront per replica, spb slots per step (tw: + a threshold wavefront; spb = 1 only so)
 int mi_launch_potts(const EllArgs &, hipStream_t);
+// potts_fast_kernels.hip: K3f, the Potts chain for models whose every slot is free of internal edges (K <= 16, 16 / 32
+// entries per variable, no size constraint); adj4 = packed adjacency with neighbour word = 2 * index
+bool mi_potts_fast_eligible(int D, int K, int min_size);
+int mi_launch_potts_fast(const EllArgs &, hipStream_t);
 
 // K1x (dense_xl_kernels.hip): dense chain for 4096 < n <= 65536, one workgroup per replica
 struct DenseXlArgs {

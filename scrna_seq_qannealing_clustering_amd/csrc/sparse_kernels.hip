@@ -376,8 +376,8 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
 // ------------------------------------------------------------------------------------------------
 // LDS per wave: labels, one byte per variable (K <= 64).  Lane q of the wave keeps cnt[q] (cluster sizes).
 // Proposal of variable i: a = l_i, b = (a + 1 + word(i,s,g,2) mod (K-1)) mod K;
-//   dE = [h_b + c cnt_b] - [h_a + c (cnt_a - 1)],  h_q = sum of S_ij over neighbours j with l_j = q
-// (h sums taken in stored neighbour order, fp32 -- oracle 2c).  Same loop economy as K2: the slot's
+//   dE = c (cnt_b - cnt_a + 1) + hd,  hd = sum over the neighbours j of S_ij ([l_j = b] - [l_j = a])
+// (ONE signed fp32 sum in stored neighbour order -- oracle 2c; round 3: it was the difference of two sums before).  Same loop economy as K2: the slot's
 // adjacency is prefetched one slot ahead; inside the slot a commit moves two cluster sizes (every lane
 // patches the sizes of ITS two labels with +-1.0, exact) and re-evaluates h only on the lanes that have the
 // moved variable among their neighbours -- found from the mover's in-slot neighbour list (`rows` / `meta`,
@@ -499,15 +499,11 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
                 if constexpr (D != 0) {
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
-                        // compare + select written out: hipcc narrows the label compare to a byte / word SDWA form, and
-                        // every SDWA compare that writes vcc is followed by an s_nop before the select may read it
-                        // (34 of them per slot); the plain 32-bit pair needs none
+                        // ONE signed sum (chain specification 2c, round 3): + S_ij for a neighbour with the target label,
+                        // - S_ij for one with the lane's own label; it is kept in hb with ha = 0 (hb - ha below is exact)
                         const int lj = lab[cur.col[k]];
-                        float ta, tb;
-                        asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(ta) : "v"(lj), "v"(la), "v"(cur.val[k]) : "vcc");
-                        asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(tb) : "v"(lj), "v"(lb), "v"(cur.val[k]) : "vcc");
-                        ha = ha + ta;
-                        hb = hb + tb;
+                        const float v = cur.val[k];
+                        hb = hb + ((lj == lb) ? v : ((lj == la) ? -v : 0.0f));
                     }
                 } else {
                     for (int k0 = 0; k0 < W; k0 += 16) {     // padding entries: (the variable itself, +0.0f)
@@ -522,8 +518,7 @@ __global__ void __launch_bounds__(256, (D <= 32 ? 4 : 2)) k_anneal_potts(EllArgs
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
                             const int lj = lab[cj[k]];
-                            ha = ha + ((lj == la) ? vj[k] : 0.0f);
-                            hb = hb + ((lj == lb) ? vj[k] : 0.0f);
+                            hb = hb + ((lj == lb) ? vj[k] : ((lj == la) ? -vj[k] : 0.0f));
                         }
                     }
                 }

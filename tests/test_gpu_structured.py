@@ -432,6 +432,69 @@ def test_potts_padded_layout_of_a_clustered_subgraph():
     assert ss.record.sample.shape[1] == len(idx)
 
 
+@pytest.mark.parametrize("K,wide", [(2, False), (3, False), (4, True), (5, False), (8, False), (8, True), (9, False), (15, False), (16, True)])
+def test_potts_fast_kernel(K, wide):
+    """K3f (csrc/potts_fast_kernels.hip): the lean Potts kernel for models whose every slot is free of internal edges --
+    the field difference as ONE table lookup and one fma per neighbour (K <= 8: a byte table through v_perm_b32, fp16
+    +-2.0 straight into v_fma_mix_f32; K <= 16: 2-bit fields through v_bfe_i32).  Equal to the oracle on the same padded
+    model (labels, accepted counts, fp64 energies) and to k_anneal_potts on the same handle: random and given initial
+    labels, a replica offset, holes, a run continued in two pieces, one constant temperature per replica; 16 and 32
+    adjacency entries per variable."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    if wide:
+        nodes, eu, ev, w, _ = graphs.synthetic_snn(700, 8, 15, 30, 5, seed=3, spread=2.5)          # degree cap 30: the 32-wide layout
+    else:
+        nodes, eu, ev, w, _ = graphs.synthetic_snn(900, 5, 15, 15, 6, seed=2, spread=3.0)
+    G = graphs.EdgeListGraph(nodes, eu, ev, w)
+    pm = models.build_dqm_potts(G, K, 0.005)
+    n = pm.num_variables
+    c_pair = float(np.float32(pm.c_pair))
+    pos, nslots, clashes = models.padded_slot_layout(pm.rowptr, pm.col)
+    assert clashes == 0
+    N = nslots * 64
+    rp, cc, vv = models.pad_csr(pm.rowptr, pm.col, f32(pm.val), pos, N)
+    absent = np.ones(N, dtype=np.uint8)
+    absent[pos] = 0
+    R = 6
+    betas = np.geomspace(0.05, 60.0, 21)
+    init = np.random.RandomState(K).randint(0, K, size=(R, n)).astype(np.uint16)
+    init_dev = np.zeros((R, N), dtype=np.uint16)
+    init_dev[:, pos] = init
+    o_rand = so.potts_csr_philox(rp, cc, vv, c_pair, N, K, R, betas, 8, lin_offset=pm.lin_offset, replica_offset=3, absent=absent)
+    o_init = so.potts_csr_philox(rp, cc, vv, c_pair, N, K, R, betas, 8, lin_offset=pm.lin_offset, init=init_dev, absent=absent)
+    with Problem.potts_csr(pm.rowptr, pm.col, f32(pm.val), c_pair, n, K, lin_offset=pm.lin_offset, order="padded",
+                           energy_model=(pm.val, pm.c_pair)) as p:
+        assert p.n_dev == N
+        for fast in (0, 2):
+            p.set_option("k3_fast", fast)
+            p.anneal(R, betas, 8, replica_offset=3)
+            assert p.kernel_name() == ("k_anneal_potts_fast<%d, %d>" % (32 if wide else 16, 8 if K <= 8 else 16) if fast == 0
+                                       else "k_anneal_potts<%d>" % (32 if wide else 16)), p.kernel_name()
+            st, en, info = p.fetch()
+            assert np.array_equal(st, o_rand[0][:, pos]) and info["accepted"] == int(o_rand[2][1])
+            assert info["proposals"] == R * len(betas) * n and np.allclose(en, pm.energies(st), rtol=1e-12)
+            p.anneal(R, betas, 8, initial_states=init)
+            st2, en2, info2 = p.fetch()
+            assert np.array_equal(st2, o_init[0][:, pos]) and info2["accepted"] == int(o_init[2][1])
+            assert np.allclose(en2, pm.energies(st2), rtol=1e-12)
+            # a run continued in two pieces == the run in one; then one constant temperature per replica
+            p.anneal(R, betas[:8], 8, replica_offset=3)
+            p.anneal(R, betas[8:], 8, replica_offset=3, continue_run=True, sweep_offset=8)
+            st3, en3, _ = p.fetch()
+            assert np.array_equal(st3, st) and np.array_equal(en3, en)
+            per = np.geomspace(0.05, 30.0, R)
+            p.anneal(R, per, 9, num_sweeps=5, sweep_offset=100)
+            st4, _, info4 = p.fetch()
+            o_per = so.potts_csr_philox(rp, cc, vv, c_pair, N, K, R, per, 9, lin_offset=pm.lin_offset, sweep_offset=100,
+                                        num_sweeps=5, absent=absent)
+            assert np.array_equal(st4, o_per[0][:, pos]) and info4["accepted"] == int(o_per[2][1])
+        # a size constraint is the general kernel's business
+        p.set_option("k3_fast", 0)
+        p.set_option("min_cluster_size", 3)
+        p.anneal(R, betas, 8, initial_states=init)
+        assert p.kernel_name().startswith("k_anneal_potts<")
+
+
 def test_csr_rank1_two_replicas_per_wavefront():
     """K2p (csrc/sparse_pair_kernels.hip): two replicas share one wavefront and one set of adjacency registers.  Same
     chain as K2: equal to the oracle on the renumbered model and to the one-replica kernel, for an odd replica count
