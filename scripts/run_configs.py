@@ -54,9 +54,10 @@ with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(f32), float(f32(pm.c_pai
                        order="slots") as p:
     p.anneal(4096, models.make_beta_schedule(S, default_potts_beta_range(pm)), 1234)
     ms = p.kernel_ms()
+    p_kernel3 = p.kernel_name()
     lab, en, info = p.fetch()
 out["config3_dqm_k8_n2638"] = {
-    "kernel": "k_anneal_potts<16>", "replicas": 4096, "sweeps": S, "kernel_ms": ms,
+    "kernel": p_kernel3, "replicas": 4096, "sweeps": S, "kernel_ms": ms,
     "updates_per_s": 4096 * S * 2638 / (ms * 1e-3), "acceptance": info["accepted"] / info["proposals"],
     "best_energy": float(en.min()), "purity_of_best": purity(lab[int(np.argmin(en))], truth), "snn_build_ms": g.timing}
 print(json.dumps(out["config3_dqm_k8_n2638"]), flush=True)
@@ -128,4 +129,4 @@ print(json.dumps(out["config5_dqm_k15_n10605_tempering"]), flush=True)
 
 for folder in ("profiles", "gpurun_out"):            # gpurun_out/ is what travels back from the GPU box
     os.makedirs(os.path.join(ROOT, folder), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, folder, "r02_configs.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, folder, "r03_configs.json"), "w"), indent=1)
