@@ -93,7 +93,11 @@ int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases
  * the MFMA kernel; 0 = never), "chunk_sweeps" (32), "k2_pair" (structured binary: 0 auto, 1 two replicas per
  * wavefront, 2 one), "k2_split" (the few-replica kernels: 0 auto = runs of up to "k2_split_max" (1024) replicas, 1 always when
  * eligible, 2 never; on models laid out in edge-free blocks of 128 / 256 seats "k2_wide" picks between ONE wavefront
- * sweeping a whole block per step (0 / 1, the default) and a workgroup of 2 / 4 wavefronts doing it (2)), "xl_batched" (dense, n > 4096: 0 auto = all replicas together on the matrix cores from 256
+ * sweeping a whole block per step (0 / 1, the default) and a workgroup of 2 / 4 wavefronts doing it (2)), "k2_tw" (0 / 1: the
+ * random words and thresholds of a sweep come from a second "threshold" wavefront of the workgroup -- the pair kernel at 16
+ * entries per variable and the one-wavefront few-replica kernel; 2: the sweeping wavefront computes them itself),
+ * "k3_fast" (Potts: 0 the lean kernel csrc/potts_fast_kernels.hip when every slot is free of internal edges, K <= 16 and no
+ * minimum size is set; 2 never), "xl_batched" (dense, n > 4096: 0 auto = all replicas together on the matrix cores from 256
  * replicas or n = 16384 up, 1 always, 2 a workgroup per replica), "xl_chain" (0 auto = the decisions and small passes of a group of eight blocks as one launch up to 512
  * replicas, 1 = one launch per block, 2 = fused always), "xl_chunk" (8) / "xl_cold_permille" (20): that batched kernel
  * hands a cooling run over to the per-replica kernel when a chunk of sweeps accepted less than this share.
