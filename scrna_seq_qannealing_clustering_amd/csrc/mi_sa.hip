@@ -551,7 +551,9 @@ static int upload_slot_ell(mi_sa_problem *p, const int32_t *rowptr, const int32_
                         if (col[e] / B == i / B) { ok = false; break; }
                 if (ok) { p->k2_free_block = B; break; }
             }
-            if (!any_general && (D == 16 || D == 32) && (size_t)slots * 256 * 8 <= 150 * 1024) {
+            // (the pair packing serves K2p and the few-replica kernels: 4 bytes of LDS per seat and replica pair / replica;
+            // whether a RUN fits the CUs' LDS is decided per launch, mi_sa_anneal)
+            if (!any_general && (D == 16 || D == 32) && (size_t)slots * 256 + 4096 <= 160 * 1024) {
                 for (int t = 0; t < slots; ++t)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int k = 0; k < D; ++k)
@@ -1054,12 +1056,19 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
             // cells: 5 % faster than K2 / K2p when every wavefront has a SIMD to itself; its 2 / 4-wavefront forms only on
             // request: measured break-even), more replicas than the chip has SIMDs -> two replicas per wavefront, else one
             const bool split_ok = p->k2_free_block >= 64 && p->d_adj4p != nullptr, pair_ok = p->d_adj4p != nullptr;
+            const bool tw = p->opt_k2_tw != 2;         // a threshold wavefront beside the sweeping one (same chain)
+            // these kernels keep 4 bytes of LDS per seat: the library's own choice takes them only when the workgroups of
+            // the run are resident in ONE round (else K2 with its bit / byte state, 16 replicas per CU at any size)
+            const long cus = p->cus > 0 ? p->cus : 256;
+            auto one_round = [&](size_t lds_per_wg, long wgs) {
+                return lds_per_wg * (size_t)((wgs + cus - 1) / cus) <= (size_t)160 * 1024;
+            };
+            const size_t cells = (size_t)p->slots * 256;
             int choice = 0;
             if (p->opt_k2_split == 1 && split_ok) choice = 2;
             else if (p->opt_k2_pair == 1 && pair_ok) choice = 1;
-            else if (p->opt_k2_split != 2 && split_ok && R <= p->opt_k2_split_max) choice = 2;
-            else if (p->opt_k2_pair != 2 && pair_ok && R > 1024) choice = 1;
-            const bool tw = p->opt_k2_tw != 2;         // a threshold wavefront beside the sweeping one (same chain)
+            else if (p->opt_k2_split != 2 && split_ok && R <= p->opt_k2_split_max && one_round(cells + 2048, R)) choice = 2;
+            else if (p->opt_k2_pair != 2 && pair_ok && R > 1024 && one_round(cells + (tw && p->D == 16 ? 4096 : 0), (R + 1) / 2)) choice = 1;
             if (choice == 2 && p->k2_free_block > 64 && p->opt_k2_wide != 2 && (p->D == 16 || p->k2_free_block == 128)) {
                 // blocks of 128 / 256 edge-free seats, few replicas: ONE wavefront sweeps a block per step
                 a.adj4 = p->d_adj4p;

@@ -98,7 +98,11 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
         const_cast<uint32_t *>(a.meta), 0, slots * 256, 0x00020000);
     struct SlotAdj { u32x4 col[G]; u32x4 val[G]; uint32_t meta; };
     const int lane16 = lane * 16;
+#ifdef MI_K3F_DBG_NOFETCH   /* timing only (wrong chain): slot 0's adjacency serves every slot, no vector-memory traffic in the sweep */
+    auto fetch_real = [&](int t) {
+#else
     auto fetch_adj = [&](int t) {
+#endif
         SlotAdj p;
         const int tt = t < slots ? t : slots - 1;
         const int soff = tt * (G * 2048);
@@ -111,6 +115,11 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
         p.meta = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, lane * 4, tt * 256, 0);
         return p;
     };
+
+#ifdef MI_K3F_DBG_NOFETCH
+    const SlotAdj adj0 = fetch_real(0);
+    auto fetch_adj = [&](int) { return adj0; };
+#endif
 
     // w mod (K-1) without the integer division: q = mulhi(w, floor(2^32 / d)) is floor(w / d) or one less
     const uint32_t dK = (uint32_t)(K - 1);
@@ -136,7 +145,11 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
             if (g0 == 0) asm volatile("ds_read_u16 %0, %1" : "=v"(own) : "v"(i * 2));
 #pragma unroll
             for (int k = 0; k < 16; ++k)
+#ifdef MI_K3F_DBG_LINEAR   /* timing only: conflict-free gather addresses */
+                asm volatile("ds_read_u16 %0, %1" : "=v"(sel[k]) : "v"((cur.col[g0 + k / 4][k & 3] & 0x1f80u) + lane * 2));
+#else
                 asm volatile("ds_read_u16 %0, %1" : "=v"(sel[k]) : "v"(cur.col[g0 + k / 4][k & 3]));
+#endif
             if (g0 == 0) {
                 asm volatile("" : "+v"(w0c));                       // (keeps the threshold arithmetic behind the reads' issue)
                 thr = neglog_u(w0c) * T;
@@ -235,11 +248,13 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
             // (the LDS operations of a wavefront execute in order: the next slot's reads of the sizes see them)
             const uint32_t newc = select_by_mask(own, enc_label<KM>(lb), A);
             asm volatile("ds_write_b16 %0, %1" :: "v"(i * 2), "v"(newc) : "memory");
+#ifndef MI_K3F_DBG_NOATOMICS   /* (timing only: cluster sizes never move) */
             asm volatile("s_mov_b64 exec, %0\n\t"
                          "ds_add_u32 %1, %3\n\t"
                          "ds_sub_u32 %2, %3\n\t"
                          "s_mov_b64 exec, -1"
                          :: "s"(A), "v"(cnt_base + lb * 4u), "v"(cnt_base + la * 4u), "v"(1u) : "memory");
+#endif
         }
     };
 

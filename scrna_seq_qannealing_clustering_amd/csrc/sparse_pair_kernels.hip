@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
     const uint8_t *init = static_cast<const uint8_t *>(a.init);
     uint32_t *cell = reinterpret_cast<uint32_t *>(lds);
     // TW: the ring of thresholds behind the cells: 2 groups x 4 slots x 64 lanes x (thrA, thrB)
-    const uint32_t ring_lane = (((uint32_t)slots * 256u + 4095u) & ~4095u) + (uint32_t)lane * 8u;
+    const uint32_t ring_lane = (uint32_t)slots * 256u + (uint32_t)lane * 8u;
 
     if constexpr (TW) {
         if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) {
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
     uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     float TA = 1.0f, TB = 1.0f;
     const float cp = a.c_pair;
-    uint32_t ring_at = ring_lane;                                   // TW: this lane's thresholds of the group being swept
+    uint32_t ring_buf = 0u;                                         // TW: which half of the ring holds the group being swept
 
     // one slot for both replicas; `wordA` / `wordB` = this slot's random words.
     // Order of a slot: (1) the LDS reads are ISSUED -- the lane's own cell and the 16 neighbour cells; (2) while they are in
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
                 asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"(cur.col[g0 + k / 4][k & 3]));
 #endif
             if (g0 == 0 && TW) {
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(thr2) : "v"(ring_at), "n"(C * 512));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(thr2) : "v"(ring_lane + ring_buf), "n"(C * 512));
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(word[4]), "+v"(word[5]),
                                "+v"(word[6]), "+v"(word[7]), "+v"(word[8]), "+v"(word[9]), "+v"(word[10]), "+v"(word[11]),
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
                     if (t + 3 < slots) slot_body(integral_constant<int, 3>{}, t + 3, Q, wa[3], wb[3]);
                 }
             }
-            if constexpr (TW) ring_at ^= 2048u;
+            if constexpr (TW) ring_buf ^= 2048u;
         }
         accepted += (unsigned long long)accA + (liveB ? (unsigned long long)accB : 0ull);
         accA = accB = 0;
@@ -361,10 +361,8 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
 template <typename KernelT>
 int launch_pair(KernelT kernel, const EllArgs &a, bool tw, hipStream_t st)
 {
-    // 4 bytes per variable; TW: the ring of thresholds behind them (its two halves are told apart by address bit 11:
-    // the cells end on a multiple of 256 bytes, so the ring starts on a multiple of 4096 behind some padding)
-    size_t lds = (size_t)a.slots * 256;
-    if (tw) lds = ((lds + 4095) / 4096) * 4096 + 4096;
+    // 4 bytes per variable; TW: the two-deep ring of thresholds behind them (2 x 4 slots x 64 lanes x 8 bytes)
+    const size_t lds = (size_t)a.slots * 256 + (tw ? 4096 : 0);
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1 pair kernel: n = %d exceeds the state LDS budget", a.n);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -380,6 +378,9 @@ int launch_pair(KernelT kernel, const EllArgs &a, bool tw, hipStream_t st)
 int mi_launch_csr_rank1_pair(const EllArgs &a, bool tw, hipStream_t st)
 {
     if (!a.adj4) return fail(MI_EHIP, "csr_rank1 pair kernel: packed adjacency missing");
+    // the ring costs LDS: beyond 64 slots only seven workgroups (14 replicas) fit a CU, and a run that fills the chip
+    // (16 replicas per CU) would take two rounds -- such models keep the kernel without a threshold wavefront
+    if (tw && ((size_t)a.slots * 256 + 4096) * 8 > 160 * 1024 && a.R > 2 * 7 * 256) tw = false;
     if (a.D == 16 && tw) return launch_pair(k_anneal_csr_rank1_pair<16, true>, a, true, st);
     if (a.D == 16) return launch_pair(k_anneal_csr_rank1_pair<16, false>, a, false, st);
     if (a.D == 32) return launch_pair(k_anneal_csr_rank1_pair<32, false>, a, false, st);

@@ -21,7 +21,7 @@ def layout_block_for(n: int, num_reads: int, max_degree: int = 16):
     coming from the workgroup's second wavefront a two-slot step takes 1.77 times a one-slot step) -- which large sparse
     graphs do (n = 2638: 22 blocks against 42 slots) and small or clustered ones, whose block count is set by the
     colours they need, do not."""
-    if num_reads > 1024 or max_degree > 32 or n > 4608 or n < 1024:      # (below ~1000 variables the colours decide)
+    if num_reads > 1024 or max_degree > 32 or n > 16384 or n < 1024:     # (below ~1000 variables the colours decide)
         return 64
     return "auto"
 

@@ -432,6 +432,39 @@ def test_potts_padded_layout_of_a_clustered_subgraph():
     assert ss.record.sample.shape[1] == len(idx)
 
 
+def test_mid_size_model_on_the_cell_state_kernels():
+    """Models beyond 4608 variables (the kidney graph of the reference has 10 605 cells) keep 4 bytes of LDS per seat on
+    the pair / few-replica kernels, so the library takes those only when the workgroups of a run are resident in one
+    round: 500 reads -> K2w with its threshold wavefront, 1100 reads -> K2p, 4096 reads -> K2 (bit state).  All equal to
+    the oracle on the padded model (states, accepted counts of the replicas compared)."""
+    from scrna_seq_qannealing_clustering_amd import graphs
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(6000, 5, 15, 15, 9, seed=7, spread=3.0)
+    m = models.build_bqm_qubo(graphs.EdgeListGraph(nodes, eu, ev, w), 0.05)
+    n = m.num_variables
+    c_pair = float(np.float32(m.c_pair))
+    pos, nslots, clashes = models.padded_slot_layout(m.rowptr, m.col)
+    assert clashes == 0
+    N = nslots * 64
+    rp, cc, vv = models.pad_csr(m.rowptr, m.col, f32(m.val), pos, N)
+    lin = np.full(N, np.inf, dtype=np.float32)
+    lin[pos] = f32(m.lin)
+    betas = np.geomspace(2e-3, 20.0, 6)
+    o = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, 6, betas, 11, replica_offset=0)
+    with Problem.csr_rank1(m.rowptr, m.col, f32(m.val), f32(m.lin), c_pair, order="padded") as p:
+        for R, tag in ((500, "k_anneal_csr_rank1_wide<16, 1, tw>"), (1100, "k_anneal_csr_rank1_pair<16, tw>"), (4096, "k_anneal_csr_rank1<16, ")):
+            p.anneal(R, betas, 11)
+            assert p.kernel_name().startswith(tag), (R, p.kernel_name())
+            st, en, info = p.fetch()
+            assert np.array_equal(st[:6], o[0][:, pos]) and np.allclose(en[:6], o[1], rtol=1e-9)
+            assert info["proposals"] == R * len(betas) * n
+            if R == 500:
+                acc500 = info["accepted"]
+                p.set_option("k2_split", 2)                       # the same run on K2: the same accepted count
+                p.anneal(R, betas, 11)
+                assert p.kernel_name().startswith("k_anneal_csr_rank1<16, ") and p.fetch()[2]["accepted"] == acc500
+                p.set_option("k2_split", 0)
+
+
 @pytest.mark.parametrize("K,wide", [(2, False), (3, False), (4, True), (5, False), (8, False), (8, True), (9, False), (15, False), (16, True)])
 def test_potts_fast_kernel(K, wide):
     """K3f (csrc/potts_fast_kernels.hip): the lean Potts kernel for models whose every slot is free of internal edges --
