@@ -1,7 +1,7 @@
 // potts_fast_kernels.hip -- K3f: the Potts (DQM) chain for the common case, built around its field sum (gfx950 only).
 //
 // Which models: every 64-seat slot free of internal edges (what the sampler's layouts give), 2 <= K <= 16 labels, 16 or
-// 32 adjacency entries per variable, no cluster-size constraint.  Everything else runs on k_anneal_potts
+// 32 adjacency entries per variable (a minimum cluster size included: template switch UM).  Everything else runs on k_anneal_potts
 // (sparse_kernels.hip) -- the same chain (oracle/sa_oracle.c 2c), bit for bit.
 //
 // Why a kernel of its own.  With four wavefronts per SIMD k_anneal_potts is bound by the NUMBER of vector instructions
@@ -51,7 +51,10 @@ __device__ __forceinline__ uint32_t select_by_mask(uint32_t if_clear, uint32_t i
     return out;
 }
 
-template <int D, int KM>
+// UM: a minimum cluster size is set (CQM_clustering.py:46-48 as a hard constraint): a move out of a cluster that would
+// be left with fewer than min_size members is rejected whatever its dE -- the size a lane sees is the one the movers
+// below it leave behind, which the same prefix scan delivers
+template <int D, int KM, bool UM>
 __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(EllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // cell of seat i at byte 2 i, then the K cluster sizes
@@ -210,7 +213,8 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
         const uint32_t pa = 0x0c0c0c00u | (la & 7u), pb = 0x0c0c0c00u | (lb & 7u);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na0), "+v"(nb0) :: "memory");
         const int d0 = nb0 - na0 + 1;                               // cnt_b - (cnt_a - 1) before any move of this slot
-        const uint64_t A0 = __ballot(__builtin_fmaf(c_eff, (float)d0, hd) < thr);
+        uint64_t A0 = __ballot(__builtin_fmaf(c_eff, (float)d0, hd) < thr);
+        if constexpr (UM) A0 &= __ballot(na0 - 1 >= a.min_size);
         if (A0 != 0ull) {                                           // wave-uniform
             // fixed-point rounds (ends by itself: a lane's decision depends on the movers below it only, so after k rounds
             // the lowest k lanes are final); only the wave-uniform mask lives across the loop
@@ -237,7 +241,14 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
                     }
                 }
                 const int d = d0 + (int)sb - (int)sa - (int)own2;
-                const uint64_t A2 = __ballot(__builtin_fmaf(c_eff, (float)d, hd) < thr);
+                uint64_t A2 = __ballot(__builtin_fmaf(c_eff, (float)d, hd) < thr);
+                if constexpr (UM) {
+                    // members of the lane's cluster when its turn comes: the start value + the net change by the movers
+                    // BELOW it = the inclusive scan byte minus the lane's own contribution (0 as a mover, 1 otherwise)
+                    // minus the (lane) ones of the lanes below
+                    const int size_a = na0 + (int)sa + (int)(own2 >> 1) - (lane + 1);
+                    A2 &= __ballot(size_a - 1 >= a.min_size);
+                }
                 uint64_t df = A2 ^ A;
                 asm("" : "+s"(df));
                 A = A2;
@@ -326,7 +337,8 @@ int launch_potts_fast(KernelT kernel, const EllArgs &a, int km, hipStream_t st)
 
 bool mi_potts_fast_eligible(int D, int K, int min_size)
 {
-    return (D == 16 || D == 32) && K >= 2 && K <= 16 && min_size <= 0;
+    (void)min_size;                                                 // (any: the kernels with the size test are built too)
+    return (D == 16 || D == 32) && K >= 2 && K <= 16;
 }
 
 // a.adj4 = the packed adjacency with neighbour word = 2 * index (the byte address of the neighbour's 16-bit cell)
@@ -334,12 +346,13 @@ int mi_launch_potts_fast(const EllArgs &a, hipStream_t st)
 {
     if (!a.adj4) return fail(MI_EHIP, "potts fast kernel: packed adjacency missing");
     if (!mi_potts_fast_eligible(a.D, a.K, a.min_size)) return fail(MI_EUNSUPPORTED, "potts fast kernel: not built for this model");
+    const bool um = a.min_size > 0;
     if (a.K <= 8 && !getenv("MI_K3F_KM16")) {
-        if (a.D == 16) return launch_potts_fast(k_anneal_potts_fast<16, 8>, a, 8, st);
-        return launch_potts_fast(k_anneal_potts_fast<32, 8>, a, 8, st);
+        if (a.D == 16) return um ? launch_potts_fast(k_anneal_potts_fast<16, 8, true>, a, 8, st) : launch_potts_fast(k_anneal_potts_fast<16, 8, false>, a, 8, st);
+        return um ? launch_potts_fast(k_anneal_potts_fast<32, 8, true>, a, 8, st) : launch_potts_fast(k_anneal_potts_fast<32, 8, false>, a, 8, st);
     }
-    if (a.D == 16) return launch_potts_fast(k_anneal_potts_fast<16, 16>, a, 16, st);
-    return launch_potts_fast(k_anneal_potts_fast<32, 16>, a, 16, st);
+    if (a.D == 16) return um ? launch_potts_fast(k_anneal_potts_fast<16, 16, true>, a, 16, st) : launch_potts_fast(k_anneal_potts_fast<16, 16, false>, a, 16, st);
+    return um ? launch_potts_fast(k_anneal_potts_fast<32, 16, true>, a, 16, st) : launch_potts_fast(k_anneal_potts_fast<32, 16, false>, a, 16, st);
 }
 
 }  // namespace mi_sa_impl

@@ -471,8 +471,8 @@ def test_potts_fast_kernel(K, wide):
     the field difference as ONE table lookup and one fma per neighbour (K <= 8: a byte table through v_perm_b32, fp16
     +-2.0 straight into v_fma_mix_f32; K <= 16: 2-bit fields through v_bfe_i32).  Equal to the oracle on the same padded
     model (labels, accepted counts, fp64 energies) and to k_anneal_potts on the same handle: random and given initial
-    labels, a replica offset, holes, a run continued in two pieces, one constant temperature per replica; 16 and 32
-    adjacency entries per variable."""
+    labels, a replica offset, holes, a run continued in two pieces, one constant temperature per replica, a minimum
+    cluster size; 16 and 32 adjacency entries per variable."""
     from scrna_seq_qannealing_clustering_amd import graphs
     if wide:
         nodes, eu, ev, w, _ = graphs.synthetic_snn(700, 8, 15, 30, 5, seed=3, spread=2.5)          # degree cap 30: the 32-wide layout
@@ -521,11 +521,21 @@ def test_potts_fast_kernel(K, wide):
             o_per = so.potts_csr_philox(rp, cc, vv, c_pair, N, K, R, per, 9, lin_offset=pm.lin_offset, sweep_offset=100,
                                         num_sweeps=5, absent=absent)
             assert np.array_equal(st4, o_per[0][:, pos]) and info4["accepted"] == int(o_per[2][1])
-        # a size constraint is the general kernel's business
-        p.set_option("k3_fast", 0)
-        p.set_option("min_cluster_size", 3)
-        p.anneal(R, betas, 8, initial_states=init)
-        assert p.kernel_name().startswith("k_anneal_potts<")
+        # a minimum cluster size (CQM_clustering.py:46-48 as a hard constraint): the same two kernels against the oracle
+        ms = max(2, n // (3 * K))
+        init_ms = (np.arange(R * n).reshape(R, n) % K).astype(np.uint16)          # every cluster well above the minimum
+        init_ms_dev = np.zeros((R, N), dtype=np.uint16)
+        init_ms_dev[:, pos] = init_ms
+        o_ms = so.potts_csr_philox(rp, cc, vv, c_pair, N, K, R, betas, 8, lin_offset=pm.lin_offset, init=init_ms_dev,
+                                   min_size=ms, absent=absent)
+        p.set_option("min_cluster_size", ms)
+        for fast in (0, 2):
+            p.set_option("k3_fast", fast)
+            p.anneal(R, betas, 8, initial_states=init_ms)
+            assert p.kernel_name().startswith("k_anneal_potts_fast<" if fast == 0 else "k_anneal_potts<")
+            st5, _, info5 = p.fetch()
+            assert np.array_equal(st5, o_ms[0][:, pos]) and info5["accepted"] == int(o_ms[2][1])
+            assert min(np.bincount(row, minlength=K).min() for row in st5) >= ms
 
 
 def test_csr_rank1_two_replicas_per_wavefront():
