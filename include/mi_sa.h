@@ -135,6 +135,16 @@ int mi_sa_plan_slot_layout(const int32_t *rowptr, const int32_t *col, int n, int
  * of the penalty term), takes no proposal.  Call before the first anneal of the problem. */
 int mi_sa_problem_set_absent(mi_sa_problem *p, const uint8_t *absent);
 
+/* Structured binary models: positive integer WEIGHTS of the uniform pair term,
+ *     E(z) = offset + sum_i lin_i z_i + sum_{i<j} S_ij z_i z_j + c_pair sum_{i<j} w_i w_j z_i z_j
+ * -- the shape a squared linear constraint with slack variables gives a QUBO, lam (sum_i x_i + sum_j c_j t_j - ub)^2:
+ * what `clustering_bqm_3` builds through bqm.add_linear_inequality_constraint (BQM_clustering.py:373-380), w = 1 on the
+ * cells and c_j on the slack bits, so that model runs on the structured kernels instead of the dense ones.
+ * weights[i] >= 1 for every variable of the problem (the value at a hole is ignored).  The variables whose weight
+ * is not 1 must lie inside ONE 64-variable slot that holds no variable of weight 1 (holes apart) and must have no
+ * sparse couplings: MI_EINVAL otherwise.  Call before the first anneal of the problem. */
+int mi_sa_problem_set_pair_weights(mi_sa_problem *p, const int32_t *weights);
+
 /* Diagnostic: copies the first `words` (<= 16) 64-bit statistics words of the last run ([0..2] as in
  * mi_sa_fetch; [8..12] per-phase cycle sums of builds compiled with -DMI_K2_PROFILE, otherwise 0; with words = 16,
  * [14] / [15] = chunks of the last scheduled dense run served by the workgroup kernel / the MFMA kernel). */

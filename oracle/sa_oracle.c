@@ -272,11 +272,18 @@ int orc_sa_dense_philox(const float *Qs, int n, double offset, int R, uint32_t r
  * include/mi_sa.h: mi_sa_plan_slot_layout): it is 0 from the start -- an explicit initial state included -- and
  * takes no proposal; the random numbers stay addressed by position, so the holes only shift them. */
 #define ORC_SLOT 64
-int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val, const float *lin,
-                            float c_pair, int n, double offset, int R, uint32_t replica_offset,
-                            int num_sweeps, const double *betas, uint64_t seed, const uint8_t *init,
-                            int resync_interval, uint8_t *out_states, double *out_energy,
-                            uint64_t *out_stats, uint32_t sweep_offset, int betas_per_replica)
+/* wgt (nullable): positive integer WEIGHTS a_i of the pair term,
+ *     E(z) = offset + sum_i lin_i z_i + sum_{i<j} S_ij z_i z_j + c sum_{i<j} a_i a_j z_i z_j
+ * -- the shape of a squared linear constraint with slack variables, lam (sum_i x_i + sum_j c_j t_j - ub)^2
+ * (BQM_clustering.py:373-380 through dimod's add_linear_inequality_constraint: a_i = 1 on the cells, c_j on the
+ * slack bits).  The chain carries A = sum_j a_j z_j as an integer:  f_i = g_i + (c * (float)a_i) * (float)(A - a_i z_i)
+ * (fp32: one multiply for the coefficient, one multiply and one add, no contraction); with a_i = 1 everywhere
+ * (wgt == NULL) this is chain (2b) as it always was, bit for bit. */
+int orc_sa_csr_rank1_philox_w(const int *rowptr, const int *col, const float *val, const float *lin,
+                              float c_pair, int n, double offset, int R, uint32_t replica_offset,
+                              int num_sweeps, const double *betas, uint64_t seed, const uint8_t *init,
+                              int resync_interval, uint8_t *out_states, double *out_energy,
+                              uint64_t *out_stats, uint32_t sweep_offset, int betas_per_replica, const int *wgt)
 {
     uint64_t tot_prop = 0, tot_acc = 0;
     const int nb = betas_per_replica ? R : num_sweeps;
@@ -287,12 +294,12 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
         uint32_t gid = replica_offset + (uint32_t)r;
         uint8_t *x = out_states + (size_t)r * n;
         float g[ORC_SLOT];
-        int S = 0;
+        long S = 0;                                                   /* sum_j a_j x_j */
         if (init) memcpy(x, init + (size_t)r * n, (size_t)n);
         else
             for (int i = 0; i < n; ++i) x[i] = (uint8_t)(chain_word(seed, (uint32_t)i, 0, gid, 1) >> 31);
         for (int i = 0; i < n; ++i) if (isinf(lin[i])) x[i] = 0;      /* a hole of a padded layout (see above) */
-        for (int i = 0; i < n; ++i) S += x[i];
+        for (int i = 0; i < n; ++i) S += x[i] ? (wgt ? wgt[i] : 1) : 0;
         for (int s = 0; s < num_sweeps; ++s) {
             float T = temps[betas_per_replica ? r : s];
             for (int i0 = 0; i0 < n; i0 += ORC_SLOT) {
@@ -305,15 +312,17 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
                 }
                 for (int i = i0; i < i1; ++i) {
                     if (isinf(lin[i])) continue;                      /* hole: no variable sits here, nothing is proposed */
+                    const int ai = wgt ? wgt[i] : 1;
                     float thr = orc_neglog_u(chain_word(seed, (uint32_t)i, (uint32_t)s + sweep_offset, gid, 0)) * T;
-                    float fi = g[i - i0] + c_pair * (float)(S - (int)x[i]);
+                    float cw = c_pair * (float)ai;                    /* (a_i = 1: c_pair itself) */
+                    float fi = g[i - i0] + cw * (float)(S - (x[i] ? ai : 0));
                     float dE = x[i] ? -fi : fi;
                     ++tot_prop;
                     if (dE < thr) {
                         float sgn = x[i] ? -1.0f : 1.0f;
                         for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
                             if (col[e] >= i0 && col[e] < i1) g[col[e] - i0] = g[col[e] - i0] + sgn * val[e];
-                        S += x[i] ? -1 : 1;
+                        S += x[i] ? -ai : ai;
                         x[i] ^= 1;
                         ++tot_acc;
                     }
@@ -322,22 +331,35 @@ int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val,
         }
         (void)resync_interval;
         double E = 0.0;
-        long cnt = 0;
+        double A = 0.0, A2 = 0.0;                                     /* sum a_i x_i, sum a_i^2 x_i (exact in fp64) */
         for (int i = 0; i < n; ++i) {
             if (!x[i]) continue;
-            ++cnt;
+            const double ai = wgt ? (double)wgt[i] : 1.0;
+            A += ai;
+            A2 += ai * ai;
             E += (double)lin[i];
             double acc = 0.0;
             for (int e = rowptr[i]; e < rowptr[i + 1]; ++e)
                 if (x[col[e]]) acc += (double)val[e];
             E += 0.5 * acc;
         }
-        E += (double)c_pair * 0.5 * (double)cnt * (double)(cnt - 1);
+        E += (double)c_pair * 0.5 * (A * A - A2);                     /* (a = 1: cnt (cnt - 1) / 2) */
         out_energy[r] = E + offset;
     }
     free(temps);
     if (out_stats) { out_stats[0] += tot_prop; out_stats[1] += tot_acc; }
     return 0;
+}
+
+int orc_sa_csr_rank1_philox(const int *rowptr, const int *col, const float *val, const float *lin,
+                            float c_pair, int n, double offset, int R, uint32_t replica_offset,
+                            int num_sweeps, const double *betas, uint64_t seed, const uint8_t *init,
+                            int resync_interval, uint8_t *out_states, double *out_energy,
+                            uint64_t *out_stats, uint32_t sweep_offset, int betas_per_replica)
+{
+    return orc_sa_csr_rank1_philox_w(rowptr, col, val, lin, c_pair, n, offset, R, replica_offset, num_sweeps, betas, seed,
+                                     init, resync_interval, out_states, out_energy, out_stats, sweep_offset,
+                                     betas_per_replica, NULL);
 }
 
 /* How often does fp32 chain arithmetic decide differently from fp64 (neal computes in doubles)?  Runs chain (2b) exactly

@@ -70,7 +70,7 @@ def sa_dense_philox(Qs, R, betas, seed, offset=0.0, replica_offset=0, init=None,
 
 
 def sa_csr_rank1_philox(rowptr, col, val, lin, c_pair, R, betas, seed, offset=0.0,
-                        replica_offset=0, init=None, resync_interval=0, sweep_offset=0, num_sweeps=None):
+                        replica_offset=0, init=None, resync_interval=0, sweep_offset=0, num_sweeps=None, weights=None):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     col = np.ascontiguousarray(col, dtype=np.int32)
     val = np.ascontiguousarray(val, dtype=np.float32)
@@ -82,12 +82,14 @@ def sa_csr_rank1_philox(rowptr, col, val, lin, c_pair, R, betas, seed, offset=0.
     stats = np.zeros(2, dtype=np.uint64)
     if init is not None:
         init = np.ascontiguousarray(init, dtype=np.uint8)
-    rc = lib().orc_sa_csr_rank1_philox(
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.int32)
+    rc = lib().orc_sa_csr_rank1_philox_w(
         _p(rowptr, C.c_int), _p(col, C.c_int), _p(val, C.c_float), _p(lin, C.c_float),
         C.c_float(c_pair), C.c_int(n), C.c_double(offset), C.c_int(R), C.c_uint32(replica_offset),
         C.c_int(len(betas) if num_sweeps is None else num_sweeps), _p(betas, C.c_double), C.c_uint64(seed),
         _p(init, C.c_uint8), C.c_int(resync_interval), _p(states, C.c_uint8), _p(energy, C.c_double),
-        _p(stats, C.c_uint64), C.c_uint32(sweep_offset), C.c_int(0 if num_sweeps is None else 1))
+        _p(stats, C.c_uint64), C.c_uint32(sweep_offset), C.c_int(0 if num_sweeps is None else 1), _p(weights, C.c_int))
     assert rc == 0
     return states, energy, stats
 

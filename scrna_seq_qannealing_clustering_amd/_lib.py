@@ -46,6 +46,7 @@ def _declare(lib):
         "mi_sa_set_option": (C.c_int, [vp, C.c_char_p, C.c_long]),
         "mi_sa_plan_slot_order": (C.c_int, [i32p, i32p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
         "mi_sa_problem_set_absent": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
+        "mi_sa_problem_set_pair_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
         "mi_sa_plan_slot_layout": (C.c_int, [i32p, i32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mi_sa_problem_set_energy_model_f64": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]),
         "mi_sa_debug_pace": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_int]),
@@ -99,7 +100,7 @@ EXPORTS = (
     "mi_last_error", "mi_abi_version", "mi_device_count", "mi_device_info",
     "mi_sa_problem_create_dense_f32", "mi_sa_problem_create_csr_rank1_f32",
     "mi_sa_problem_create_potts_csr_f32", "mi_sa_problem_destroy", "mi_sa_problem_info",
-    "mi_sa_set_option", "mi_sa_plan_slot_order", "mi_sa_plan_slot_layout", "mi_sa_problem_set_absent", "mi_sa_problem_set_energy_model_f64", "mi_sa_debug_pace", "mi_sa_debug_stats", "mi_sa_anneal", "mi_sa_anneal_ex", "mi_sa_tempering_begin", "mi_sa_tempering_exchange", "mi_sa_tempering_exchange_dev", "mi_sa_device_results", "mi_sa_tempering_state", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_last_launch_count", "mi_sa_last_kernel_name", "mi_sa_fetch", "mi_sa_best",
+    "mi_sa_set_option", "mi_sa_plan_slot_order", "mi_sa_plan_slot_layout", "mi_sa_problem_set_absent", "mi_sa_problem_set_pair_weights", "mi_sa_problem_set_energy_model_f64", "mi_sa_debug_pace", "mi_sa_debug_stats", "mi_sa_anneal", "mi_sa_anneal_ex", "mi_sa_tempering_begin", "mi_sa_tempering_exchange", "mi_sa_tempering_exchange_dev", "mi_sa_device_results", "mi_sa_tempering_state", "mi_sa_sync", "mi_sa_last_kernel_ms", "mi_sa_last_launch_count", "mi_sa_last_kernel_name", "mi_sa_fetch", "mi_sa_best",
     "mi_multi_gpu_anneal", "mi_multi_gpu_best", "mi_multi_gpu_fetch", "mi_sa_qubo_dense_f32", "mi_energy_dense_f32", "mi_energy_dense_f64", "mi_energy_dense_f32_ex",
     "mi_snn_build_f32", "mi_snn_build_ex_f32", "mi_snn_build_rounded_f32", "mi_snn_fetch_codes", "mi_snn_info", "mi_snn_fetch", "mi_snn_kernel_ms", "mi_snn_destroy",
     "mi_jaccard_cluster_stats",

@@ -182,10 +182,13 @@ struct mi_sa_problem {
     uint2 *d_rows = nullptr;                 // K2: row-major adjacency, in-slot neighbours first
     uint32_t *d_meta = nullptr;              // K2 / K3: in-slot count | degree << 8 | absent << 31
     std::vector<uint32_t> h_meta;            // host copy (mi_sa_problem_set_absent)
+    std::vector<uint8_t> h_hole;             // structured binary: positions whose linear term is +inf (mi_sa_problem_set_pair_weights)
     uint4 *d_adj4 = nullptr;                 // K2: packed slot adjacency (see EllArgs::adj4)
     uint4 *d_adj4p = nullptr;                // K2p (two replicas per wavefront): the same with neighbour word = 4 * index; null = not eligible
     uint32_t *d_slot_flags = nullptr;        // K2: slots with internal edges
     int k2_state_bytes = 0;                  // K2: byte-per-variable state (16 replicas x n bytes fit one CU's LDS)
+    int32_t *d_wgt = nullptr;                // K2 family: the 64 pair-term weights of the weighted slot (mi_sa_problem_set_pair_weights)
+    int wslot = -1;                          // ... its index; -1: every weight is 1
     int k2_free_block = 0;                   // K2s: widest block of seats (256 / 128 / 64; 0 = none) that holds no edge anywhere in the model
     int cus = 0;
     // run buffers
@@ -759,6 +762,8 @@ int mi_sa_problem_create_csr_rank1_f32(const int32_t *rowptr, const int32_t *col
         // the lanes past n carry lin = +inf: their dE is +inf, never accepted (K2 has no per-lane bound check)
         std::vector<float> hl((size_t)p->slots * 64, INFINITY);
         for (int i = 0; i < n; ++i) hl[i] = lin[i];
+        p->h_hole.assign((size_t)n, 0);
+        for (int i = 0; i < n; ++i) p->h_hole[(size_t)i] = std::isinf(lin[i]) ? 1 : 0;
         HIP_TRY(hipMalloc((void **)&p->d_lin, hl.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(p->d_lin, hl.data(), hl.size() * sizeof(float), hipMemcpyHostToDevice));
         return MI_OK;
@@ -830,6 +835,50 @@ int mi_sa_problem_set_absent(mi_sa_problem *p, const uint8_t *absent)
     });
 }
 
+int mi_sa_problem_set_pair_weights(mi_sa_problem *p, const int32_t *weights)
+{
+    if (!p || !weights) return fail(MI_EINVAL, "NULL argument");
+    if (p->kind != MI_KIND_CSR_RANK1)
+        return fail(MI_EUNSUPPORTED, "pair-term weights: structured binary (CSR + uniform pair) problems only");
+    return guarded([&]() -> int {
+        int wslot = -1;
+        for (int i = 0; i < p->n; ++i) {
+            if (p->h_meta[(size_t)i] >> 31) continue;          // (never set for this kind; holes are marked by lin = +inf)
+            const bool hole = !p->h_hole.empty() && p->h_hole[(size_t)i];
+            if (hole) continue;
+            if (weights[i] < 1) return fail(MI_EINVAL, "weight %d of variable %d: weights are positive integers", weights[i], i);
+            if (weights[i] > (1 << 20)) return fail(MI_EINVAL, "weight %d of variable %d exceeds 2^20", weights[i], i);
+            if (weights[i] == 1) continue;
+            if (p->h_rowptr[(size_t)i + 1] != p->h_rowptr[(size_t)i])
+                return fail(MI_EINVAL, "variable %d has weight %d and sparse couplings: weighted variables couple through the pair term only", i, weights[i]);
+            if (wslot >= 0 && wslot != i / 64)
+                return fail(MI_EINVAL, "variables with weights other than 1 in slots %d and %d: they must share one 64-variable slot", wslot, i / 64);
+            wslot = i / 64;
+        }
+        std::vector<int32_t> hw(64, 0);
+        if (wslot >= 0) {
+            for (int l = 0; l < 64; ++l) {
+                const int i = wslot * 64 + l;
+                if (i >= p->n || (!p->h_hole.empty() && p->h_hole[(size_t)i])) continue;
+                hw[(size_t)l] = weights[i];
+            }
+            // a variable of weight 1 may share the slot (it is swept by the same serial loop) -- but it must have no sparse
+            // couplings either: the loop does not update neighbours
+            for (int l = 0; l < 64; ++l) {
+                const int i = wslot * 64 + l;
+                if (i < p->n && hw[(size_t)l] != 0 && p->h_rowptr[(size_t)i + 1] != p->h_rowptr[(size_t)i])
+                    return fail(MI_EINVAL, "variable %d shares the weighted slot %d and has sparse couplings", i, wslot);
+            }
+        }
+        HIP_TRY(hipSetDevice(p->device));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (!p->d_wgt) HIP_TRY(hipMalloc((void **)&p->d_wgt, 64 * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(p->d_wgt, hw.data(), 64 * sizeof(int32_t), hipMemcpyHostToDevice));
+        p->wslot = wslot;
+        return MI_OK;
+    });
+}
+
 int mi_sa_problem_set_energy_model_f64(mi_sa_problem *p, const double *val, const double *lin, double c_pair)
 {
     return guarded([&]() -> int { return set_energy_model_impl(p, val, lin, c_pair); });
@@ -840,7 +889,7 @@ int mi_sa_problem_destroy(mi_sa_problem *p)
     if (!p) return MI_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_xg, p->d_pt_rung, p->d_pt_betas, p->d_pt_energy, p->d_pt_ladder, p->d_pt_temps, p->d_pt_stats, p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
+    void *bufs[] = {p->d_wgt, p->d_xg, p->d_pt_rung, p->d_pt_betas, p->d_pt_energy, p->d_pt_ladder, p->d_pt_temps, p->d_pt_stats, p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -1035,6 +1084,7 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         a.sweep_offset = sweep_offset; a.temps_per_replica = per_replica ? 1 : 0;
         a.rows = p->d_rows; a.meta = p->d_meta; a.adj4 = p->d_adj4; a.slot_flags = p->d_slot_flags; a.state_bytes = p->k2_state_bytes; a.waves_override = p->opt_k2_waves; a.min_size = p->opt_min_cluster_size;
         a.ell_val64 = p->d_ell_val64; a.lin64 = p->d_lin64; a.c_pair64 = p->c_pair64;
+        a.wgt = p->d_wgt; a.wslot = p->kind == MI_KIND_CSR_RANK1 ? p->wslot : -1;
         if (p->kind == MI_KIND_POTTS_CSR && init) {
             // labels must be < K: validated on the host copy (the device trusts them as cnt[] indices)
             const uint16_t *l = static_cast<const uint16_t *>(init);
@@ -1065,11 +1115,22 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
             };
             const size_t cells = (size_t)p->slots * 256;
             int choice = 0;
+            // (a model with pair-term weights: the kernels that sweep its weighted slot are K2, K2p and K2w with one slot
+            // per step beside a threshold wavefront)
+            const bool weighted = p->wslot >= 0;
+            if (weighted) {
+                if (p->opt_k2_pair != 2 && pair_ok && R > 1024 && one_round(cells + (tw && p->D == 16 ? 4096 : 0), (R + 1) / 2)) choice = 1;
+                else if (p->opt_k2_split != 2 && tw && p->opt_k2_wide != 2 && split_ok &&
+                         R <= p->opt_k2_split_max && one_round(cells + 2048, R)) choice = 2;
+            } else
             if (p->opt_k2_split == 1 && split_ok) choice = 2;
             else if (p->opt_k2_pair == 1 && pair_ok) choice = 1;
             else if (p->opt_k2_split != 2 && split_ok && R <= p->opt_k2_split_max && one_round(cells + 2048, R)) choice = 2;
             else if (p->opt_k2_pair != 2 && pair_ok && R > 1024 && one_round(cells + (tw && p->D == 16 ? 4096 : 0), (R + 1) / 2)) choice = 1;
-            if (choice == 2 && p->k2_free_block > 64 && p->opt_k2_wide != 2 && (p->D == 16 || p->k2_free_block == 128)) {
+            if (choice == 2 && weighted) {
+                a.adj4 = p->d_adj4p;                  // (an edge-free layout in wider blocks is one in 64-seat slots too)
+                rc = mi_launch_csr_rank1_wide(a, 1, true, p->stream);
+            } else if (choice == 2 && p->k2_free_block > 64 && p->opt_k2_wide != 2 && (p->D == 16 || p->k2_free_block == 128)) {
                 // blocks of 128 / 256 edge-free seats, few replicas: ONE wavefront sweeps a block per step
                 a.adj4 = p->d_adj4p;
                 rc = mi_launch_csr_rank1_wide(a, p->k2_free_block / 64, tw, p->stream);

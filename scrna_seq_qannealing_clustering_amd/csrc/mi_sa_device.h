@@ -293,7 +293,44 @@ struct EllArgs {
     const double *ell_val64;
     const double *lin64;
     double c_pair64;
+    // K2 family: weights of the uniform pair term (mi_sa_problem_set_pair_weights).  wslot >= 0: the one slot whose
+    // variables carry weights other than 1 (wgt = its 64 weights, 0 at a hole); every kernel then carries
+    // sum_j w_j z_j where it carried sum_j z_j and sweeps that slot with a serial loop.  wslot < 0: all weights 1.
+    const int32_t *wgt = nullptr;
+    int wslot = -1;
 };
+
+// The weighted slot of a structured binary model (EllArgs::wslot): a sequential sweep over its lanes -- few variables,
+// the slack bits of a squared constraint, coupled to everything through the pair term only -- with the oracle's expression
+// f = g + (c * (float)w) * (float)(A - w z).  z: the lane's bit; A: sum_j w_j z_j, updated.  Returns the mask of flips.
+__device__ __forceinline__ uint64_t weighted_slot_sweep(float g, float thr, int w, float c_pair, uint32_t z, int &A, int lane)
+{
+    const float cw = c_pair * (float)w;
+    uint64_t todo = __ballot(w != 0), flipped = 0ull;
+    uint32_t zz = z;
+    while (todo != 0ull) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1ull;
+        const float f = g + cw * (float)(A - w * (int)zz);
+        const float dE = zz ? -f : f;
+        if ((__ballot(dE < thr) >> l) & 1ull) {                     // wave-uniform: lane l accepts
+            const int wl = __builtin_amdgcn_readlane(w, l);
+            const int zl = __builtin_amdgcn_readlane((int)zz, l);
+            A += zl ? -wl : wl;
+            if (lane == l) zz ^= 1u;
+            flipped |= 1ull << l;
+        }
+    }
+    return flipped;
+}
+
+// sum over the wavefront of a small non-negative integer (initialisation / epilogue of the weighted slot)
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
 int mi_launch_csr_rank1_pair(const EllArgs &, bool tw, hipStream_t);   // sparse_pair_kernels.hip: two replicas per wavefront (tw: + a threshold wavefront)
 int mi_launch_csr_rank1_split(const EllArgs &, int nw, hipStream_t);   // sparse_split_kernels.hip: nw wavefronts per replica

@@ -73,6 +73,12 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
     const uint8_t *init = static_cast<const uint8_t *>(a.init);
     const uint2 *rows = a.rows;
 
+    // (pair-term weights, mi_sa_problem_set_pair_weights: S is sum_j w_j x_j; only the lanes of ONE slot carry weights
+    // other than 1, and that slot is swept by a serial loop -- weighted_slot_sweep)
+    const int wl = a.wslot >= 0 ? a.wgt[lane] : 0;
+    auto slot_sum = [&](int t, uint64_t m) -> int {
+        return t == a.wslot ? (int)wave_sum_i64(((m >> lane) & 1ull) ? (long long)wl : 0ll) : __popcll(m);
+    };
     int S = 0;
     if (init) {
         for (int t = 0; t < slots; ++t) {
@@ -81,7 +87,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
             if constexpr (XS == 2) reinterpret_cast<half_t *>(lds)[i] = (half_t)(float)((m >> lane) & 1ull);
             else if constexpr (XS == 1) lds[i] = (char)((m >> lane) & 1ull);
             else if (lane == 0) xm[t] = m;
-            S += __popcll(m);
+            S += slot_sum(t, m);
         }
     } else {
         for (int tg = 0; tg * 4 < slots; ++tg) {
@@ -97,7 +103,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
                 if constexpr (XS == 2) reinterpret_cast<half_t *>(lds)[t * 64 + lane] = (half_t)(float)((m >> lane) & 1ull);
                 else if constexpr (XS == 1) lds[t * 64 + lane] = (char)((m >> lane) & 1ull);
                 else if (lane == 0) xm[t] = m;
-                S += __popcll(m);
+                S += slot_sum(t, m);
             }
         }
     }
@@ -229,7 +235,11 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         const uint32_t sgnbit = xi << 31;                     // dE = x ? -f : f
         uint64_t todo = ~0ull, flipped = 0ull;
         bool mine = false;                                    // this lane's variable flips in this slot
-        if (!general) {
+        if (t == a.wslot) {
+            // ---- the slot of the weighted variables: a serial sweep (few lanes, no sparse couplings) ----
+            flipped = weighted_slot_sweep(gi, thr, wl, a.c_pair, xi, S, lane);
+            mine = (flipped >> lane) & 1ull;
+        } else if (!general) {
             // ---- no variable of this slot has a neighbour inside it: decisions depend on s alone -------------
             // Sequentially, lane i sees s = S + d_i with d_i = sum over the ACCEPTING lanes j < i of (+1 if x_j = 0,
             // -1 if x_j = 1), and accepts iff  +-(g_i + c (float)(S + d_i - x_i)) < thr_i  (the oracle's expression,
@@ -303,7 +313,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         }
         if (flipped) {                                        // wave-uniform
             accepted += (unsigned long long)__popcll(flipped);
-            if (general) mine = (flipped >> lane) & 1ull;
+            if (general && t != a.wslot) mine = (flipped >> lane) & 1ull;
             // toggling a state cell is one XOR of the word read at the top of the slot
             if constexpr (XS == 2) { if (mine) reinterpret_cast<uint16_t *>(lds)[i] = (uint16_t)(own ^ 0x3c00u); }
             else if constexpr (XS == 1) { if (mine) lds[i] = (char)(own ^ 1u); }
@@ -342,7 +352,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
 
     // ---- epilogue: states out, exact fp64 energy ----
     uint8_t *dst = static_cast<uint8_t *>(a.states) + (size_t)r * n;
-    int cnt = 0;
+    long long cnt = 0, cnt2 = 0;                             // sum_j w_j x_j and sum_j w_j^2 x_j (both the count when w = 1)
     double e = 0.0;
     for (int t = 0; t < slots; ++t) {
         const int i = t * 64 + lane;
@@ -350,7 +360,13 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
                                    : (XS == 1 ? __ballot(lds[i] != 0) : xm[t]);
         const int on = (int)((m >> lane) & 1ull);
         if (i < n) dst[i] = (uint8_t)on;
-        cnt += __popcll(m);
+        if (t == a.wslot) {
+            cnt += wave_sum_i64(on ? (long long)wl : 0ll);
+            cnt2 += wave_sum_i64(on ? (long long)wl * wl : 0ll);
+        } else {
+            cnt += __popcll(m);
+            cnt2 += __popcll(m);
+        }
         if (!on) continue;
         double acc = 0.0;
         for (int k = 0; k < W; ++k) {
@@ -366,7 +382,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
     e = wave_sum_f64(e);
     if (lane == 0) {
         const double cp = a.ell_val64 ? a.c_pair64 : (double)a.c_pair;
-        a.energy[r] = e + cp * 0.5 * (double)cnt * (double)(cnt - 1) + a.offset;
+        a.energy[r] = e + cp * 0.5 * ((double)cnt * (double)cnt - (double)cnt2) + a.offset;     // (w = 1: cnt (cnt - 1) / 2 pairs)
         atomicAdd(&a.stats[1], accepted);
     }
 }

@@ -93,6 +93,9 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
         }
     }
 
+    // (pair-term weights, mi_sa_problem_set_pair_weights: SA / SB are sum_j w_j x_j; the one slot whose lanes carry weights
+    // other than 1 is swept by a serial loop -- weighted_slot_sweep)
+    const int wl = a.wslot >= 0 ? a.wgt[lane] : 0;
     int SA = 0, SB = 0;
     for (int tg = 0; tg * 4 < slots; ++tg) {
         uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
@@ -115,8 +118,13 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
                 xb = real && (wb[c] >> 31);
             }
             cell[i] = (xa ? 0x3c00u : 0u) | (xb ? 0x3c000000u : 0u);
-            SA += __popcll(__ballot(xa));
-            SB += __popcll(__ballot(xb));
+            if (t == a.wslot) {
+                SA += (int)wave_sum_i64(xa ? (long long)wl : 0ll);
+                SB += (int)wave_sum_i64(xb ? (long long)wl : 0ll);
+            } else {
+                SA += __popcll(__ballot(xa));
+                SB += __popcll(__ballot(xb));
+            }
         }
     }
 
@@ -229,6 +237,19 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
             }
         }
         const uint32_t xiA = (own >> 13) & 1u, xiB = own >> 29;     // 0x3c00 -> 1
+        if (t == a.wslot) {
+            // ---- the slot of the weighted variables: a serial sweep per replica (few lanes, no sparse couplings) ----
+            const uint64_t FA = weighted_slot_sweep(gA, thrA, wl, cp, xiA, SA, lane);
+            const uint64_t FB = weighted_slot_sweep(gB, thrB, wl, cp, xiB, SB, lane);
+            accA += (uint32_t)__popcll(FA);
+            accB += (uint32_t)__popcll(FB);
+            uint32_t fA, fB;
+            asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(fA) : "v"(0x3c00u), "s"(FA));
+            asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(fB) : "v"(0x3c000000u), "s"(FB));
+            cell[i] = own ^ fA ^ fB;
+            K2P_TICK(t_rounds);
+            return;
+        }
         const uint64_t XA = __ballot((own & 0xffffu) != 0u), XB = __ballot((own >> 16) != 0u);
         const uint32_t sgA = xiA << 31, sgB = xiB << 31;            // dE = x ? -f : f
         const f32x2_t gs = {__uint_as_float(__float_as_uint(gA) ^ sgA), __uint_as_float(__float_as_uint(gB) ^ sgB)};
@@ -326,13 +347,20 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
         const int r = rep ? rB : rA;
         const int sh = rep ? 16 : 0;
         uint8_t *dst = static_cast<uint8_t *>(a.states) + (size_t)r * n;
-        int cnt = 0;
+        long long cnt = 0, cnt2 = 0;                               // sum_j w_j x_j, sum_j w_j^2 x_j
         double e = 0.0;
         for (int t = 0; t < slots; ++t) {
             const int i = t * 64 + lane;
             const bool on = ((cell[i] >> sh) & 0xffffu) != 0u;
             if (i < n) dst[i] = (uint8_t)on;
-            cnt += __popcll(__ballot(on));
+            if (t == a.wslot) {
+                cnt += wave_sum_i64(on ? (long long)wl : 0ll);
+                cnt2 += wave_sum_i64(on ? (long long)wl * wl : 0ll);
+            } else {
+                const int c1 = __popcll(__ballot(on));
+                cnt += c1;
+                cnt2 += c1;
+            }
             if (!on) continue;
             double acc = 0.0;
             for (int k = 0; k < D; ++k) {
@@ -346,7 +374,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
         e = wave_sum_f64(e);
         if (lane == 0) {
             const double cp64 = a.ell_val64 ? a.c_pair64 : (double)a.c_pair;
-            a.energy[r] = e + cp64 * 0.5 * (double)cnt * (double)(cnt - 1) + a.offset;
+            a.energy[r] = e + cp64 * 0.5 * ((double)cnt * (double)cnt - (double)cnt2) + a.offset;
         }
     }
     if (lane == 0) atomicAdd(&a.stats[1], accepted);

@@ -455,6 +455,9 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
         __builtin_amdgcn_s_setprio(3);
     }
 
+    // (pair-term weights, mi_sa_problem_set_pair_weights: S is sum_j w_j x_j; the one slot whose lanes carry weights other
+    // than 1 is swept by a serial loop -- weighted_slot_sweep)
+    const int wl = a.wslot >= 0 ? a.wgt[lane] : 0;
     int S = 0;
     for (int t = 0; t < slots; ++t) {
         const int i = t * 64 + lane;
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
             x = real && ((c == 0 ? iw[0] : (c == 1 ? iw[1] : (c == 2 ? iw[2] : iw[3]))) >> 31);
         }
         reinterpret_cast<uint32_t *>(lds)[i] = x ? 0x3c00u : 0u;
-        S += __popcll(__ballot(x));
+        S += t == a.wslot ? (int)wave_sum_i64(x ? (long long)wl : 0ll) : __popcll(__ballot(x));
     }
 
     constexpr int G = D / 4;
@@ -603,8 +606,17 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
 #pragma unroll
         for (int j = 0; j < SPB; ++j) {
             const int i = (t0 + j) * 64 + lane;
-            const uint64_t X = __ballot(own[j] != 0u);
             const uint32_t xi = own[j] >> 13;                       // 0x3c00 -> 1
+            if (t0 + j == a.wslot) {
+                // ---- the slot of the weighted variables: a serial sweep (few lanes, no sparse couplings) ----
+                const uint64_t F = weighted_slot_sweep(gi[j], thr[j], wl, cp, xi, S, lane);
+                acc32 += (uint32_t)__popcll(F);
+                uint32_t tg2;
+                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(tg2) : "v"(0x3c00u), "s"(F));
+                asm volatile("ds_write_b32 %0, %1" :: "v"(i * 4), "v"(own[j] ^ tg2) : "memory");
+                continue;
+            }
+            const uint64_t X = __ballot(own[j] != 0u);
             const uint32_t sgnbit = xi << 31;                       // dE = x ? -f : f
             const float gs = __uint_as_float(__float_as_uint(gi[j]) ^ sgnbit);
             const float cs = __uint_as_float(__float_as_uint(cp) ^ sgnbit);
@@ -656,13 +668,20 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
     // ---- epilogue: states out, exact fp64 energy (the sums of k_anneal_csr_rank1) ----
     uint8_t *dst = static_cast<uint8_t *>(a.states) + (size_t)r * n;
     const uint32_t *cell = reinterpret_cast<const uint32_t *>(lds);
-    int cnt = 0;
+    long long cnt = 0, cnt2 = 0;                                    // sum_j w_j x_j, sum_j w_j^2 x_j
     double e = 0.0;
     for (int t = 0; t < slots; ++t) {
         const int i = t * 64 + lane;
         const bool on = cell[i] != 0u;
         if (i < n) dst[i] = (uint8_t)on;
-        cnt += __popcll(__ballot(on));
+        if (t == a.wslot) {
+            cnt += wave_sum_i64(on ? (long long)wl : 0ll);
+            cnt2 += wave_sum_i64(on ? (long long)wl * wl : 0ll);
+        } else {
+            const int c1 = __popcll(__ballot(on));
+            cnt += c1;
+            cnt2 += c1;
+        }
         if (!on) continue;
         double acc = 0.0;
         for (int k = 0; k < D; ++k) {
@@ -676,7 +695,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
     e = wave_sum_f64(e);
     if (lane == 0) {
         const double cp64 = a.ell_val64 ? a.c_pair64 : (double)a.c_pair;
-        a.energy[r] = e + cp64 * 0.5 * (double)cnt * (double)(cnt - 1) + a.offset;
+        a.energy[r] = e + cp64 * 0.5 * ((double)cnt * (double)cnt - (double)cnt2) + a.offset;
         atomicAdd(&a.stats[1], accepted);
     }
 }

@@ -70,7 +70,7 @@ class Problem:
 
     @classmethod
     def csr_rank1(cls, rowptr, col, val, lin, c_pair: float, offset: float = 0.0,
-                  device: int = 0, order: Optional[str] = None, energy_model=None, block=64) -> "Problem":
+                  device: int = 0, order: Optional[str] = None, energy_model=None, block=64, weights=None) -> "Problem":
         """``order="slots"`` renumbers the variables on the device so that the 64 variables a wavefront
         sweeps together are (as far as possible) mutually non-adjacent -- the kernel's integer fast path
         (models.slot_independent_order).  States go in and come out in the CALLER's order either way; the
@@ -86,7 +86,17 @@ class Problem:
         the sampler's choice.
 
         ``energy_model=(val64, lin64, c_pair64)``: the caller's fp64 coefficients (same CSR structure); the
-        reported energies are then evaluated on the device in that model (the chain itself runs in fp32)."""
+        reported energies are then evaluated on the device in that model (the chain itself runs in fp32).
+
+        ``weights`` (positive integers, ``order="padded"`` only): weights of the pair term, ``c_pair a_i a_j`` on pair
+        (i, j) -- the slack bits of a squared linear constraint (models.add_size_window_penalty).  The variables whose
+        weight is not 1 (at most 64, without sparse couplings) get a 64-seat slot of their own behind the others."""
+        if weights is not None:
+            weights = np.asarray(weights, dtype=np.int64)
+            if np.all(weights == 1):
+                weights = None
+        if weights is not None:
+            return cls._csr_rank1_weighted(rowptr, col, val, lin, c_pair, offset, device, order, energy_model, weights)
         perm = None
         val64 = lin64 = None
         if energy_model is not None:
@@ -151,6 +161,62 @@ class Problem:
             prob = cls(h, _lib.KIND_CSR_RANK1, n, 2, device, perm=perm)
         if val64 is not None:
             prob._set_energy_model(val64, lin64, float(energy_model[2]), len(val))
+        return prob
+
+    @classmethod
+    def _csr_rank1_weighted(cls, rowptr, col, val, lin, c_pair, offset, device, order, energy_model, weights) -> "Problem":
+        """The padded layout of a model with pair-term weights: the unit-weight variables as usual (64-seat slots free of
+        internal edges), the others -- few, no sparse couplings -- in one more slot; mi_sa_problem_set_pair_weights."""
+        from .models import pad_csr, padded_slot_layout
+        if order != "padded":
+            raise ValueError("a model with pair-term weights needs order='padded'")
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        col = np.asarray(col, dtype=np.int64)
+        n_caller = len(lin)
+        deg = np.diff(rowptr)
+        heavy = np.flatnonzero(weights != 1)
+        light = np.flatnonzero(weights == 1)
+        if np.any(weights < 1) or len(heavy) > 64 or np.any(deg[heavy] != 0):
+            raise ValueError("pair-term weights: positive integers; at most 64 variables with a weight other than 1, "
+                             "and those without sparse couplings")
+        # the layout of the unit-weight variables alone (the others have no edges): their CSR renumbered 0 .. len(light) - 1
+        renum = np.full(n_caller, -1, dtype=np.int64)
+        renum[light] = np.arange(len(light))
+        rp_l = np.concatenate([[0], np.cumsum(deg[light])]).astype(np.int32)
+        keep = np.repeat(weights == 1, deg)
+        seats_l, nslots, _ = padded_slot_layout(rp_l, renum[col[keep]].astype(np.int32), slot=64)
+        seats = np.empty(n_caller, dtype=np.int64)
+        seats[light] = seats_l
+        seats[heavy] = nslots * 64 + np.arange(len(heavy))
+        n_dev = (nslots + 1) * 64
+        val64 = lin64 = None
+        if energy_model is not None:
+            val64, lin64 = np.asarray(energy_model[0], dtype=np.float64), np.asarray(energy_model[1], dtype=np.float64)
+            rp, cc, vv, val64 = pad_csr(rowptr, col, val, seats, n_dev, also=val64)
+            l64 = np.zeros(n_dev, dtype=np.float64)
+            l64[seats] = lin64
+            lin64 = l64
+        else:
+            rp, cc, vv = pad_csr(rowptr, col, val, seats, n_dev)
+        lpad = np.full(n_dev, np.inf, dtype=np.float32)
+        lpad[seats] = np.asarray(lin, dtype=np.float32)
+        rp = np.ascontiguousarray(rp, dtype=np.int32)
+        cc = np.ascontiguousarray(cc, dtype=np.int32)
+        vv = np.ascontiguousarray(vv, dtype=np.float32)
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.mi_sa_problem_create_csr_rank1_f32(
+            _ptr(rp, C.c_int32), _ptr(cc, C.c_int32), _ptr(vv, C.c_float),
+            _ptr(lpad, C.c_float), float(c_pair), n_dev, float(offset), int(device), C.byref(h)))
+        prob = cls(h, _lib.KIND_CSR_RANK1, n_caller, 2, device, seats=seats, n_dev=n_dev)
+        wdev = np.ones(n_dev, dtype=np.int32)
+        wdev[seats] = weights
+        rc = lib.mi_sa_problem_set_pair_weights(h, _ptr(wdev, C.c_int32))
+        if rc:
+            prob.close()
+            _lib.check(rc)
+        if val64 is not None:
+            prob._set_energy_model(val64, lin64, float(energy_model[2]), len(vv))
         return prob
 
     @classmethod

@@ -214,6 +214,10 @@ class QuboModel:
     offset: float = 0.0
     info: Dict[str, Any] = field(default_factory=dict)
     _dense: Optional[np.ndarray] = None  # set when the model was given densely (general Q)
+    # positive integer weights a_i of the pair term: the coefficient of pair i<j is c_pair a_i a_j + S_ij (None: all 1).
+    # A squared linear constraint with slack bits has this shape (add_size_window_penalty); the structured kernels take
+    # it (include/mi_sa.h: mi_sa_problem_set_pair_weights) when the weights other than 1 are few and have no edges.
+    weights: Optional[np.ndarray] = None
 
     @property
     def num_variables(self) -> int:
@@ -223,7 +227,11 @@ class QuboModel:
         if self._dense is not None:
             return self._dense.astype(dtype, copy=False)
         n = self.num_variables
-        Qs = np.full((n, n), 0.5 * self.c_pair, dtype=np.float64)
+        if self.weights is None:
+            Qs = np.full((n, n), 0.5 * self.c_pair, dtype=np.float64)
+        else:
+            a = np.asarray(self.weights, dtype=np.float64)
+            Qs = 0.5 * self.c_pair * np.outer(a, a)
         rows = np.repeat(np.arange(n), np.diff(self.rowptr))
         Qs[rows, self.col] += 0.5 * self.val
         Qs[np.arange(n), np.arange(n)] = self.lin
@@ -250,8 +258,12 @@ class QuboModel:
         Xf = X.astype(np.float64)
         if self._dense is not None:
             return np.einsum("ri,ri->r", Xf @ self._dense, Xf) + self.offset
-        s = Xf.sum(axis=1)
-        e = Xf @ self.lin + self.c_pair * 0.5 * s * (s - 1.0) + self.offset
+        if self.weights is None:
+            s = Xf.sum(axis=1)
+            e = Xf @ self.lin + self.c_pair * 0.5 * s * (s - 1.0) + self.offset
+        else:                                                   # c sum_{i<j} a_i a_j x_i x_j = c/2 ((a.x)^2 - a^2.x)
+            a = np.asarray(self.weights, dtype=np.float64)
+            e = Xf @ self.lin + self.c_pair * 0.5 * ((Xf @ a) ** 2 - Xf @ (a * a)) + self.offset
         rows = np.repeat(np.arange(self.num_variables), np.diff(self.rowptr))
         e += 0.5 * np.einsum("re,re,e->r", Xf[:, rows], Xf[:, self.col], self.val)
         return e
@@ -571,7 +583,9 @@ def add_size_window_penalty(model: QuboModel, lb: float, ub: float, lagrange_mul
     ``BinaryQuadraticModel`` look-alike): binary slack variables ``t_j`` with positive coefficients ``c_j`` spanning
     ``[0, int(ub - lb)]`` and the energy ``lagrange * (sum_i x_i + sum_j c_j t_j - ub)^2`` with ``ub`` kept fractional
     (the reference passes ``n / 6``: for n = 256, lb = 40 the sizes 41-43 cost the minimum ``lagrange / 9``, not zero).
-    ``ValueError`` when ``ub < lb``.  Returned as a dense-backed QuboModel over ``variables + slack``."""
+    ``ValueError`` when ``ub < lb``.  Returned over ``variables + slack``: in STRUCTURED form (the model's sparse part + a
+    uniform pair term ``2 lagrange`` with integer weights 1 / ``c_j``) when the model itself is sparse without a pair
+    term -- the reference's `clustering_bqm_3` -- else dense-backed."""
     from .bqm import inequality_slack
     n = model.num_variables
     coeffs, ub_c = inequality_slack([1] * n, lb, ub, 0, slack_prefix.rstrip("_"))
@@ -583,13 +597,25 @@ def add_size_window_penalty(model: QuboModel, lb: float, ub: float, lagrange_mul
     ns = len(coeffs)
     a = np.concatenate([np.ones(n), np.asarray(coeffs, dtype=np.float64)])     # sum a_i z_i - ub_c
     N = n + ns
+    variables = list(model.variables) + [slack_prefix + str(i) for i in range(ns)]
+    if (model._dense is None and model.c_pair == 0.0 and model.weights is None and lam != 0.0 and ns <= 64
+            and all(float(c) == int(c) and int(c) >= 1 for c in coeffs)):
+        # STRUCTURED form: lam (a.z - ub_c)^2 = lam sum_i (a_i^2 - 2 ub_c a_i) z_i + 2 lam sum_{i<j} a_i a_j z_i z_j + lam ub_c^2
+        # -- the sparse cut term of the model plus a WEIGHTED uniform pair term (c_pair = 2 lam, weights a): slack bits have
+        # no sparse couplings, so the structured kernels run it (mi_sa_problem_set_pair_weights) instead of the dense ones
+        ai = np.concatenate([np.ones(n, dtype=np.int64), np.asarray(coeffs, dtype=np.int64)])
+        lin = np.concatenate([model.lin, np.zeros(ns)]) + lam * (a * a - 2.0 * ub_c * a)
+        rowptr = np.concatenate([model.rowptr, np.full(ns, model.rowptr[-1], dtype=model.rowptr.dtype)])
+        return QuboModel(variables, lin, rowptr, model.col, model.val, c_pair=2.0 * lam,
+                         offset=model.offset + lam * ub_c * ub_c,
+                         info=dict(model.info, slack=ns, lb=lb_c, ub=ub_c),
+                         weights=None if np.all(ai == 1) else ai)
     Qs = np.zeros((N, N), dtype=np.float64)
     Qs[:n, :n] = model.dense_Qs()
     # lam (a.z - ub_c)^2 = lam [ sum_i a_i^2 z_i + 2 sum_{i<j} a_i a_j z_i z_j - 2 ub_c a.z + ub_c^2 ]
     outer = lam * np.outer(a, a)
     Qs += outer - np.diag(np.diag(outer))
     Qs[np.arange(N), np.arange(N)] += lam * (a * a - 2.0 * ub_c * a)
-    variables = list(model.variables) + [slack_prefix + str(i) for i in range(ns)]
     out = QuboModel(variables, np.diag(Qs).copy(), np.zeros(N + 1, dtype=np.int32),
                     np.zeros(0, dtype=np.int32), np.zeros(0), c_pair=0.0,
                     offset=model.offset + lam * ub_c * ub_c,
@@ -615,18 +641,23 @@ def default_beta_range(model: QuboModel, rel_zero: float = 1e-9) -> Tuple[float,
         nzJ = np.abs(off[off != 0.0]) / 2.0
     else:
         rows = np.repeat(np.arange(n), np.diff(model.rowptr))
+        # pair (i, j) carries c_pair a_i a_j + S_ij (a = 1 without weights: the expressions below reduce to c_pair (n - 1) etc.)
+        a = np.ones(n) if model.weights is None else np.asarray(model.weights, dtype=np.float64)
+        others = a * (a.sum() - a)                                  # a_i * sum_{j != i} a_j
+        uni = model.c_pair * a[rows] * a[model.col]                 # the uniform part on the stored pairs
         pair_sum = np.zeros(n)
         np.add.at(pair_sum, rows, model.val)
-        pair_sum += model.c_pair * (n - 1)
+        pair_sum += model.c_pair * others
         h = model.lin / 2.0 + pair_sum / 4.0
-        full = model.val + model.c_pair
+        full = model.val + uni
         abs_sum = np.zeros(n)
-        np.add.at(abs_sum, rows, np.abs(full) - abs(model.c_pair))
-        abs_sum += abs(model.c_pair) * (n - 1)
+        np.add.at(abs_sum, rows, np.abs(full) - np.abs(uni))
+        abs_sum += abs(model.c_pair) * others
         J_abs_rowsum = abs_sum / 4.0
         cand = [np.abs(full[full != 0.0]) / 4.0]
-        if model.c_pair != 0.0 and len(model.val) < n * (n - 1):
-            cand.append(np.array([abs(model.c_pair) / 4.0]))
+        if model.c_pair != 0.0 and len(model.val) < n * (n - 1) and n >= 2:
+            two = np.partition(a, 1)[:2]                            # the smallest product of two weights
+            cand.append(np.array([abs(model.c_pair) * two[0] * two[1] / 4.0]))
         nzJ = np.concatenate(cand) if cand else np.zeros(0)
     maxJ = float(nzJ.max()) if len(nzJ) else 0.0
     scale = max(maxJ, float(np.max(np.abs(h))) if n else 0.0)

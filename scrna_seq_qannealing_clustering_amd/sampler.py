@@ -232,7 +232,7 @@ class MI355XSampler:
                                      model.lin.astype(np.float32), float(np.float32(model.c_pair)),
                                      offset=model.offset, device=self.device, order="padded",
                                      energy_model=(model.val, model.lin, model.c_pair),
-                                     block=layout_block_for(n, num_reads, max_deg))
+                                     block=layout_block_for(n, num_reads, max_deg), weights=model.weights)
         else:
             dense64 = model.dense_Qs()
             prob = Problem.dense(_symmetric_f32(dense64), offset=model.offset, device=self.device)

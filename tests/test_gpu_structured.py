@@ -432,6 +432,69 @@ def test_potts_padded_layout_of_a_clustered_subgraph():
     assert ss.record.sample.shape[1] == len(idx)
 
 
+@pytest.mark.parametrize("lb,ub_div", [(20, 2.5), (40, 6.0)])
+def test_weighted_pair_term_size_window_model(lb, ub_div):
+    """`clustering_bqm_3`'s model (BQM_clustering.py:363-380: cut term + a squared size window with slack bits) in its
+    STRUCTURED form: sparse couplings + a uniform pair term with integer weights (1 on the cells, the slack coefficients
+    on the slack bits; models.add_size_window_penalty, mi_sa_problem_set_pair_weights).  The slack bits sit in a slot of
+    their own that the kernels sweep serially.  K2w beside its threshold wavefront, K2 and K2p all equal the oracle's
+    weighted chain on the same padded model (states, accepted counts, fp64 energies); the sampler takes this path."""
+    from scrna_seq_qannealing_clustering_amd import graphs, MI355XSampler
+    nodes, eu, ev, w, _ = graphs.synthetic_snn(300, 5, 15, 15, 3, seed=5, spread=3.0)
+    G = graphs.EdgeListGraph(nodes, eu, ev, w)
+    base = models.build_bqm3_cut_qubo(G, k=8)
+    n0 = base.num_variables
+    pen = models.add_size_window_penalty(base, lb=lb, ub=n0 / ub_div, lagrange_multiplier=0.05 * float(np.sum(w)) / n0)
+    assert pen._dense is None and pen.c_pair != 0.0
+    if ub_div == 2.5:
+        assert pen.weights is not None and pen.weights.max() > 1               # 100 slack units: 1, 2, 4, ... and a remainder
+    n = pen.num_variables
+    X = np.random.RandomState(1).randint(0, 2, size=(5, n))
+    assert np.allclose(pen.energies(X), np.einsum("ri,ij,rj->r", X, pen.dense_Qs(), X) + pen.offset, rtol=1e-12)
+    c_pair = float(np.float32(pen.c_pair))
+    betas = models.make_beta_schedule(12, models.default_beta_range(pen))
+    with Problem.csr_rank1(pen.rowptr, pen.col, f32(pen.val), f32(pen.lin), c_pair, offset=pen.offset, order="padded",
+                           energy_model=(pen.val, pen.lin, pen.c_pair), weights=pen.weights) as p:
+        seats, N = p._inv, p.n_dev
+        rp, cc, vv = models.pad_csr(pen.rowptr, pen.col, f32(pen.val), seats, N)
+        lin = np.full(N, np.inf, dtype=np.float32)
+        lin[seats] = f32(pen.lin)
+        wdev = np.ones(N, dtype=np.int32)
+        if pen.weights is not None:
+            wdev[seats] = pen.weights
+            assert len(set(seats[pen.weights != 1] // 64)) == 1                  # one slot of their own
+        R = 6
+        init = np.random.RandomState(3).randint(0, 2, size=(R, n)).astype(np.uint8)
+        init_dev = np.zeros((R, N), dtype=np.uint8)
+        init_dev[:, seats] = init
+        o_rand = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, R, betas, 21, offset=pen.offset, replica_offset=2, weights=wdev)
+        o_init = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, R, betas, 21, offset=pen.offset, init=init_dev, weights=wdev)
+        for opts, tag in (({}, "k_anneal_csr_rank1_wide<16, 1, tw>"), ({"k2_split": 2}, "k_anneal_csr_rank1<16, ")):
+            for k, v in opts.items():
+                p.set_option(k, v)
+            p.anneal(R, betas, 21, replica_offset=2)
+            assert p.kernel_name().startswith(tag), p.kernel_name()
+            st, en, info = p.fetch()
+            assert np.array_equal(st, o_rand[0][:, seats]) and info["accepted"] == int(o_rand[2][1])
+            assert info["proposals"] == R * len(betas) * n and np.allclose(en, pen.energies(st), rtol=1e-12)
+            assert np.allclose(en, o_rand[1], rtol=1e-5)                       # (the oracle sums the fp32 coefficients)
+            p.anneal(R, betas, 21, initial_states=init)
+            st2, en2, info2 = p.fetch()
+            assert np.array_equal(st2, o_init[0][:, seats]) and info2["accepted"] == int(o_init[2][1])
+        p.set_option("k2_split", 0)
+        # many replicas: two per wavefront (the first six compared; their ids are the same)
+        o6 = so.sa_csr_rank1_philox(rp, cc, vv, lin, c_pair, R, betas, 21, offset=pen.offset, weights=wdev)
+        for tw in (0, 2):
+            p.set_option("k2_tw", tw)
+            p.anneal(1100, betas, 21)
+            assert p.kernel_name() == ("k_anneal_csr_rank1_pair<16, tw>" if tw == 0 else "k_anneal_csr_rank1_pair<16>")
+            stp, enp, _ = p.fetch()
+            assert np.array_equal(stp[:R], o6[0][:, seats]) and np.allclose(enp, pen.energies(stp), rtol=1e-12)
+    ss = MI355XSampler().sample_qubo(pen, num_reads=64, num_sweeps=300, seed=9)
+    assert ss.info["kernel"] == "csr_rank1" and list(ss.variables) == list(pen.variables)
+    assert np.allclose(ss.record.energy, pen.energies(ss.record.sample.astype(np.uint8)), rtol=1e-12)
+
+
 def test_mid_size_model_on_the_cell_state_kernels():
     """Models beyond 4608 variables (the kidney graph of the reference has 10 605 cells) keep 4 bytes of LDS per seat on
     the pair / few-replica kernels, so the library takes those only when the workgroups of a run are resident in one

@@ -229,3 +229,34 @@ def test_oracle_matches_bruteforce_small(kat):
     betas = models.make_beta_schedule(200, models.default_beta_range(m))
     st, en, _ = so.sa_dense_philox(Qs.astype(np.float32), 32, betas, 7)
     assert en.min() == pytest.approx(g["min_E"], abs=1e-4)
+
+
+def test_oracle_weighted_pair_term():
+    """Chain (2b) with pair-term weights (oracle/sa_oracle.c: orc_sa_csr_rank1_philox_w; the structured form of
+    BQM_clustering.py:373-380's squared size window): with every weight 1 it IS chain (2b), bit for bit; with weights its
+    energies are those of the dense matrix c a_i a_j + S_ij, and on a 14-variable instance a long cold run ends in the
+    brute-force optimum."""
+    from scrna_seq_qannealing_clustering_amd import models
+    rs = np.random.RandomState(11)
+    n = 14
+    edges = [(i, j) for i in range(10) for j in range(i + 1, 10) if rs.rand() < 0.35]
+    w = rs.uniform(0.2, 1.0, size=len(edges))
+    base = models.QuboModel(list(range(10)), *models._cut_qubo_parts(10, np.array([e[0] for e in edges]), np.array([e[1] for e in edges]), w, 8)[:1],
+                            *models._csr_from_edges(10, np.array([e[0] for e in edges]), np.array([e[1] for e in edges]),
+                                                    models._cut_qubo_parts(10, np.array([e[0] for e in edges]), np.array([e[1] for e in edges]), w, 8)[1]))
+    pen = models.add_size_window_penalty(base, lb=2, ub=10.0, lagrange_multiplier=1.5)      # slack range 8: weights 1, 2, 4, 1
+    assert pen.weights is not None and pen.num_variables == n and sorted(pen.weights[10:].tolist()) == [1, 1, 2, 4]
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    betas = np.geomspace(0.05, 30.0, 200)
+    args = (pen.rowptr, pen.col, f32(pen.val), f32(pen.lin), float(np.float32(pen.c_pair)), 16, betas, 5)
+    st, en, stats = so.sa_csr_rank1_philox(*args, offset=pen.offset, weights=pen.weights)
+    assert np.allclose(en, pen.energies(st), rtol=1e-5, atol=1e-5)
+    Qs = pen.dense_Qs()
+    allx = ((np.arange(1 << n)[:, None] >> np.arange(n)) & 1).astype(np.float64)
+    brute = np.einsum("ri,ij,rj->r", allx, Qs, allx) + pen.offset
+    assert en.min() == pytest.approx(brute.min(), rel=1e-5, abs=1e-5)
+    assert np.allclose(pen.energies(allx[:64]), brute[:64], rtol=1e-12)
+    # unit weights: the unweighted chain, bit for bit
+    s1 = so.sa_csr_rank1_philox(*args, weights=np.ones(n, dtype=np.int32))
+    s0 = so.sa_csr_rank1_philox(*args)
+    assert np.array_equal(s1[0], s0[0]) and np.array_equal(s1[1], s0[1]) and np.array_equal(s1[2], s0[2])
