@@ -1144,7 +1144,8 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
                 a.adj4 = p->d_adj4p;                  // two replicas per wavefront: half the adjacency traffic per update
                 rc = mi_launch_csr_rank1_pair(a, p->opt_k2_tw != 2 && p->D == 16, p->stream);
             } else {
-                rc = mi_launch_csr_rank1(a, p->stream);
+                // K2: every wavefront alone on its SIMD (up to 1024 replicas) -> a threshold wavefront beside it
+                rc = mi_launch_csr_rank1(a, p->stream, tw && R <= 1024 && (p->D == 16 || p->D == 32) && p->k2_state_bytes <= 1);
             }
         }
         if (rc) return rc;

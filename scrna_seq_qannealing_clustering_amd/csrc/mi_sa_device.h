@@ -298,6 +298,7 @@ struct EllArgs {
     // sum_j w_j z_j where it carried sum_j z_j and sweeps that slot with a serial loop.  wslot < 0: all weights 1.
     const int32_t *wgt = nullptr;
     int wslot = -1;
+    int ring_off = 0;          // K2 with a threshold wavefront: byte offset of the ring of thresholds in LDS (set by its launcher)
 };
 
 // The weighted slot of a structured binary model (EllArgs::wslot): a sequential sweep over its lanes -- few variables,
@@ -331,7 +332,7 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-int mi_launch_csr_rank1(const EllArgs &, hipStream_t);
+int mi_launch_csr_rank1(const EllArgs &, hipStream_t, bool tw = false);   // tw: + a threshold wavefront (runs of up to 1024 replicas; bit / byte state, 16 / 32 entries)
 int mi_launch_csr_rank1_pair(const EllArgs &, bool tw, hipStream_t);   // sparse_pair_kernels.hip: two replicas per wavefront (tw: + a threshold wavefront)
 int mi_launch_csr_rank1_split(const EllArgs &, int nw, hipStream_t);   // sparse_split_kernels.hip: nw wavefronts per replica
 int mi_launch_csr_rank1_wide(const EllArgs &, int spb, bool tw, hipStream_t);   // ... one wavefront per replica, spb slots per step (tw: + a threshold wavefront; spb = 1 only so)

@@ -56,8 +56,12 @@ __device__ __forceinline__ void slot_words(uint32_t (&w)[4], int tg, int lane, u
 // two VALU instructions per neighbour (convert, fma) instead of four (address shift, bit extract, mask, add).
 // 2: one HALF per variable (0.0 / 1.0; n <= 4608): the fma takes the half as it is (v_fma_mix_f32 widens the
 // operand exactly), ONE VALU instruction per neighbour, the same fp32 result bit for bit.
-template <int D, int XS>
-__global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllArgs a)
+// TW (round 3): a second wavefront of the workgroup computes the random words and thresholds one group of four slots
+// ahead and hands them over through a two-deep ring in LDS behind the state (k_anneal_csr_rank1_pair has the same
+// arrangement) -- for runs of up to 1024 replicas, where every wavefront has a SIMD to itself and a third of a slot's
+// instructions move to an idle one.  a.ring_off = byte offset of the ring (2 x 4 slots x 64 lanes x 4 bytes).
+template <int D, int XS, bool TW = false>
+__global__ void __launch_bounds__(TW ? 128 : 64, (TW ? 2 : (D <= 32 ? 4 : 2))) k_anneal_csr_rank1(EllArgs a)
 {
     constexpr bool XB = XS != 0;                     // state addressed per variable (byte or half), not per bit
     typedef _Float16 half_t;
@@ -72,6 +76,33 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
     uint64_t *xm = reinterpret_cast<uint64_t *>(lds);                          // bit l of xm[t] = x[64 t + l]
     const uint8_t *init = static_cast<const uint8_t *>(a.init);
     const uint2 *rows = a.rows;
+    if constexpr (TW) {
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) {
+            // ---- the threshold wavefront ----
+            uint32_t tw_w[4];
+            uint32_t buf = 0;
+            const uint32_t at0 = (uint32_t)a.ring_off + (uint32_t)lane * 4u;
+            for (int s2 = 0; s2 < a.num_sweeps; ++s2) {
+                const float T2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[a.temps_per_replica ? r : s2])));
+#pragma unroll 1
+                for (int t = 0; t < slots; t += 4) {
+                    slot_words(tw_w, t >> 2, lane, (uint32_t)s2 + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
+                    const f32x2_t l01 = neglog_u2(tw_w[0], tw_w[1]) * f32x2_t{T2, T2}, l23 = neglog_u2(tw_w[2], tw_w[3]) * f32x2_t{T2, T2};
+                    const uint32_t at = at0 + buf;
+                    asm volatile("ds_write_b32 %0, %1" :: "v"(at), "v"(l01.x) : "memory");
+                    asm volatile("ds_write_b32 %0, %1 offset:256" :: "v"(at), "v"(l01.y) : "memory");
+                    asm volatile("ds_write_b32 %0, %1 offset:512" :: "v"(at), "v"(l23.x) : "memory");
+                    asm volatile("ds_write_b32 %0, %1 offset:768" :: "v"(at), "v"(l23.y) : "memory");
+                    buf ^= 1024u;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            return;
+        }
+        __builtin_amdgcn_s_setprio(3);
+    }
+    uint32_t ring_buf = 1024u;                       // TW: the half of the ring the running group is in (toggled at its start)
 
     // (pair-term weights, mi_sa_problem_set_pair_weights: S is sum_j w_j x_j; only the lanes of ONE slot carry weights
     // other than 1, and that slot is swept by a serial loop -- weighted_slot_sweep)
@@ -149,11 +180,19 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
     int s = 0;
 
     auto slot_body = [&](int t, const SlotAdj &cur) {
-        if ((t & 3) == 0)
-            slot_words(w, t >> 2, lane, (uint32_t)s + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
+        if ((t & 3) == 0) {
+            if constexpr (TW) {
+                __builtin_amdgcn_s_barrier();                 // this group's thresholds are in the ring
+                ring_buf ^= 1024u;
+            } else {
+                slot_words(w, t >> 2, lane, (uint32_t)s + a.sweep_offset, gid, 0u, a.seed_lo, a.seed_hi);
+            }
+        }
         const int c = t & 3;
         const uint32_t wc = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
         const int i = t * 64 + lane;
+        float thr_tw = 0.0f;
+        if constexpr (TW) thr_tw = *reinterpret_cast<const float *>(lds + a.ring_off + ring_buf + (uint32_t)c * 256u + (uint32_t)lane * 4u);
         const bool general = __builtin_amdgcn_readfirstlane((int)cur.flag) != 0;   // some variable of this slot has a
                                                               // neighbour inside the slot
         K2_TICK(t_init);
@@ -217,7 +256,7 @@ __global__ void __launch_bounds__(64, (D <= 32 ? 4 : 2)) k_anneal_csr_rank1(EllA
         }
         K2_TICK(t_apply);
         // (the lanes past n carry lin = +inf: dE = +inf is never below any threshold, no per-lane bound check here)
-        const float thr = neglog_u(wc) * T;
+        const float thr = TW ? thr_tw : neglog_u(wc) * T;
         uint64_t xm_t;                                        // the slot's 64 state bits as a scalar
         uint32_t xi;
         if constexpr (XS == 2) {
@@ -777,24 +816,36 @@ int launch_sparse(KernelT kernel, const EllArgs &a, size_t lds_per_wave, hipStre
 }
 
 template <typename KernelT>
-int launch_csr_rank1(KernelT kernel, const EllArgs &a, size_t lds, hipStream_t st)
+int launch_csr_rank1(KernelT kernel, const EllArgs &a0, size_t lds, hipStream_t st, bool tw = false)
 {
-    // one wavefront = one replica = one workgroup; the only LDS is the state (a bit or a byte per variable)
+    // one wavefront = one replica = one workgroup; the only LDS is the state (a bit or a byte per variable) -- and, with a
+    // threshold wavefront beside the sweeping one, the ring of thresholds behind it
+    EllArgs a = a0;
+    if (tw) {
+        a.ring_off = (int)((lds + 15) / 16 * 16);
+        lds = (size_t)a.ring_off + 2048;
+    }
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "csr_rank1: n = %d exceeds the state LDS budget", a.n);
     if (!a.adj4 || !a.slot_flags) return fail(MI_EHIP, "csr_rank1: packed adjacency missing");
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    note_kernel("k_anneal_csr_rank1<%d, %d>", a.D <= 64 ? a.D : 0, a.state_bytes);
-    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(64), lds, st, a);
+    note_kernel(tw ? "k_anneal_csr_rank1<%d, %d, tw>" : "k_anneal_csr_rank1<%d, %d>", a.D <= 64 ? a.D : 0, a.state_bytes);
+    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(tw ? 128 : 64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
 }  // namespace
 
-int mi_launch_csr_rank1(const EllArgs &a, hipStream_t st)
+int mi_launch_csr_rank1(const EllArgs &a, hipStream_t st, bool tw)
 {
     const size_t bits = (size_t)a.slots * 8, bytes = (size_t)a.slots * 64, halves = (size_t)a.slots * 128;
+    if (tw) {          // built for the register-resident widths of large models: bit and byte state
+        if (a.state_bytes == 1 && a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, 1, true>, a, bytes, st, true);
+        if (a.state_bytes == 1 && a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, 1, true>, a, bytes, st, true);
+        if (a.state_bytes == 0 && a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, 0, true>, a, bits, st, true);
+        if (a.state_bytes == 0 && a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, 0, true>, a, bits, st, true);
+    }
     if (a.state_bytes == 2) {
         if (a.D == 16) return launch_csr_rank1(k_anneal_csr_rank1<16, 2>, a, halves, st);
         if (a.D == 32) return launch_csr_rank1(k_anneal_csr_rank1<32, 2>, a, halves, st);
