@@ -1096,7 +1096,8 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
         if (p->kind == MI_KIND_POTTS_CSR) {
             if (p->d_adj4p && p->opt_k3_fast != 2 && mi_potts_fast_eligible(p->D, p->K, a.min_size)) {
                 a.adj4 = p->d_adj4p;                  // every slot free of internal edges: the lean kernel (same chain)
-                rc = mi_launch_potts_fast(a, p->stream);
+                // (up to 1024 replicas every wavefront has a SIMD to itself: a threshold wavefront beside each)
+                rc = mi_launch_potts_fast(a, p->opt_k2_tw != 2 && R <= 1024, p->stream);
             } else {
                 rc = mi_launch_potts(a, p->stream);
             }

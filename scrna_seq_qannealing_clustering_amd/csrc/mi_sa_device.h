@@ -260,6 +260,7 @@ constexpr int kDenseNoEnergy = 4;    // not the last launch of a run: skip the e
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -340,7 +341,7 @@ int mi_launch_potts(const EllArgs &, hipStream_t);
 // potts_fast_kernels.hip: K3f, the Potts chain for models whose every slot is free of internal edges (K <= 16, 16 / 32
 // entries per variable, no size constraint); adj4 = packed adjacency with neighbour word = 2 * index
 bool mi_potts_fast_eligible(int D, int K, int min_size);
-int mi_launch_potts_fast(const EllArgs &, hipStream_t);
+int mi_launch_potts_fast(const EllArgs &, bool tw, hipStream_t);
 
 // K1x (dense_xl_kernels.hip): dense chain for 4096 < n <= 65536, one workgroup per replica
 struct DenseXlArgs {

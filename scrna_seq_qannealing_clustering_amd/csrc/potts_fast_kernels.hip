@@ -54,8 +54,12 @@ __device__ __forceinline__ uint32_t select_by_mask(uint32_t if_clear, uint32_t i
 // UM: a minimum cluster size is set (CQM_clustering.py:46-48 as a hard constraint): a move out of a cluster that would
 // be left with fewer than min_size members is rejected whatever its dE -- the size a lane sees is the one the movers
 // below it leave behind, which the same prefix scan delivers
-template <int D, int KM, bool UM>
-__global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(EllArgs a)
+// TW: a second wavefront of the workgroup computes what does not depend on the labels -- the threshold -ln(u) * T and the
+// target offset word mod (K - 1) of every proposal -- one group of four slots ahead and hands them over through a two-deep
+// ring in LDS (as k_anneal_csr_rank1_pair does): for runs of up to 1024 replicas (the sampler's default is 256 reads), where
+// every wavefront has a SIMD to itself and that work moves to an idle one.
+template <int D, int KM, bool UM, bool TW>
+__global__ void __launch_bounds__(TW ? 128 : 64, (TW ? 2 : (D == 16 ? 4 : 2))) k_anneal_potts_fast(EllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // cell of seat i at byte 2 i, then the K cluster sizes
     const int lane = threadIdx.x & 63;
@@ -66,6 +70,43 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
     const uint32_t cnt_base = (uint32_t)slots * 128u;
     int *cnt = reinterpret_cast<int *>(lds + cnt_base);
     const uint16_t *init = static_cast<const uint16_t *>(a.init);
+    // w mod (K-1) without the integer division: q = mulhi(w, floor(2^32 / d)) is floor(w / d) or one less
+    const uint32_t dK = (uint32_t)(K - 1);
+    const uint32_t magic = dK == 1u ? 0xffffffffu : (uint32_t)(0x100000000ull / dK);
+    // TW: the ring behind the cluster sizes, 2 groups x 4 slots x 64 lanes x (threshold, target offset)
+    const uint32_t ring_lane = cnt_base + 256u + (uint32_t)lane * 8u;
+    if constexpr (TW) {
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) {
+            // ---- the threshold wavefront ----
+            uint32_t pw0[4], pw2[4];
+            uint32_t buf = 0;
+            for (int s = 0; s < a.num_sweeps; ++s) {
+                float Tp = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.temps[a.temps_per_replica ? r : s])));
+                if constexpr (KM == 8) Tp = 2.0f * Tp;
+                const uint32_t sw = (uint32_t)s + a.sweep_offset;
+#pragma unroll 1
+                for (int t = 0; t < slots; t += 4) {
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gid, 0u, a.seed_lo, a.seed_hi, pw0);
+                    philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gid, 2u, a.seed_lo, a.seed_hi, pw2);
+                    const f32x2_t l01 = neglog_u2(pw0[0], pw0[1]) * f32x2_t{Tp, Tp}, l23 = neglog_u2(pw0[2], pw0[3]) * f32x2_t{Tp, Tp};
+                    const float thr4[4] = {l01.x, l01.y, l23.x, l23.y};
+                    const uint32_t at = ring_lane + buf;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint32_t rem = pw2[c] - __umulhi(pw2[c], magic) * dK;     // in [0, 2 dK)
+                        rem = rem >= dK ? rem - dK : rem;
+                        const u32x2 pk = {__float_as_uint(thr4[c]), rem};
+                        asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(at), "v"(pk), "n"(c * 512) : "memory");
+                    }
+                    buf ^= 2048u;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            return;
+        }
+        __builtin_amdgcn_s_setprio(3);
+    }
 
     // ---- initial labels (the chain's tag-1 words, or the caller's / the previous launch's states) ----
     for (int tg = 0; tg * 4 < slots; ++tg) {
@@ -124,9 +165,6 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
     auto fetch_adj = [&](int) { return adj0; };
 #endif
 
-    // w mod (K-1) without the integer division: q = mulhi(w, floor(2^32 / d)) is floor(w / d) or one less
-    const uint32_t dK = (uint32_t)(K - 1);
-    const uint32_t magic = dK == 1u ? 0xffffffffu : (uint32_t)(0x100000000ull / dK);
     const float c_eff = KM == 8 ? 2.0f * a.c_pair : a.c_pair;       // (KM = 8: the field sum comes out doubled)
     const bool narrow = K <= 4;                                     // wave-uniform: the size bytes of all clusters fill one dword
 
@@ -137,11 +175,14 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
     float T = 1.0f;
 
     typedef _Float16 half_t;
-    auto slot_body = [&](int t, const SlotAdj &cur, uint32_t w0c, uint32_t w2c) {
+    uint32_t ring_buf = 0u;                                         // TW: which half of the ring holds the group being swept
+    auto slot_body = [&](auto c_in_group, int t, const SlotAdj &cur, uint32_t w0c, uint32_t w2c) {
+        constexpr int C = decltype(c_in_group)::value;
         const int i = t * 64 + lane;
         uint32_t own;
         float hd = 0.0f;
         float thr = 0.0f;
+        u32x2 tw2 = {0u, 0u};                                       // TW: (threshold bits, target offset) from the ring
         uint32_t la = 0u, lb = 0u, tlo = 0u, thi = 0u;
 #pragma unroll
         for (int g0 = 0; g0 < G; g0 += 4) {
@@ -154,18 +195,31 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
                 asm volatile("ds_read_u16 %0, %1" : "=v"(sel[k]) : "v"(cur.col[g0 + k / 4][k & 3]));
 #endif
             if (g0 == 0) {
-                asm volatile("" : "+v"(w0c));                       // (keeps the threshold arithmetic behind the reads' issue)
-                thr = neglog_u(w0c) * T;
-                if (cur.meta >> 31) thr = -INFINITY;                // nobody sits here
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(sel[0]), "+v"(sel[1]), "+v"(sel[2]), "+v"(sel[3]), "+v"(sel[4]), "+v"(sel[5]),
-                               "+v"(sel[6]), "+v"(sel[7]), "+v"(sel[8]), "+v"(sel[9]), "+v"(sel[10]), "+v"(sel[11]),
-                               "+v"(sel[12]), "+v"(sel[13]), "+v"(sel[14]), "+v"(sel[15]), "+v"(own), "+v"(thr)
-                             :: "memory");
+                uint32_t rem;
+                if constexpr (TW) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(tw2) : "v"(ring_lane + ring_buf), "n"(C * 512));
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(sel[0]), "+v"(sel[1]), "+v"(sel[2]), "+v"(sel[3]), "+v"(sel[4]), "+v"(sel[5]),
+                                   "+v"(sel[6]), "+v"(sel[7]), "+v"(sel[8]), "+v"(sel[9]), "+v"(sel[10]), "+v"(sel[11]),
+                                   "+v"(sel[12]), "+v"(sel[13]), "+v"(sel[14]), "+v"(sel[15]), "+v"(own), "+v"(tw2)
+                                 :: "memory");
+                    thr = __uint_as_float(tw2.x);
+                    rem = tw2.y;
+                    if (cur.meta >> 31) thr = -INFINITY;            // nobody sits here
+                } else {
+                    asm volatile("" : "+v"(w0c));                   // (keeps the threshold arithmetic behind the reads' issue)
+                    thr = neglog_u(w0c) * T;
+                    if (cur.meta >> 31) thr = -INFINITY;            // nobody sits here
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(sel[0]), "+v"(sel[1]), "+v"(sel[2]), "+v"(sel[3]), "+v"(sel[4]), "+v"(sel[5]),
+                                   "+v"(sel[6]), "+v"(sel[7]), "+v"(sel[8]), "+v"(sel[9]), "+v"(sel[10]), "+v"(sel[11]),
+                                   "+v"(sel[12]), "+v"(sel[13]), "+v"(sel[14]), "+v"(sel[15]), "+v"(own), "+v"(thr)
+                                 :: "memory");
+                    rem = w2c - __umulhi(w2c, magic) * dK;          // in [0, 2 dK)
+                    rem = rem >= dK ? rem - dK : rem;
+                }
                 // the proposal: a = the lane's label, b = (a + 1 + word mod (K - 1)) mod K; and the lookup table of sigma
                 la = dec_label<KM>(own);
-                uint32_t rem = w2c - __umulhi(w2c, magic) * dK;     // in [0, 2 dK)
-                rem = rem >= dK ? rem - dK : rem;
                 lb = la + 1u + rem;                                 // in [1, 2K - 2]
                 lb = lb >= (uint32_t)K ? lb - (uint32_t)K : lb;
                 if constexpr (KM == 8) {
@@ -274,22 +328,28 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
         if constexpr (KM == 8) T = 2.0f * T;                        // (the doubled field sum against the doubled threshold)
         const uint32_t sw = (uint32_t)s + a.sweep_offset;
         SlotAdj P = fetch_adj(0), Q;
+        using std::integral_constant;
 #pragma unroll 1
         for (int t = 0; t < slots; t += 4) {
-            philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gid, 0u, a.seed_lo, a.seed_hi, w0);
-            philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gid, 2u, a.seed_lo, a.seed_hi, w2);
+            if constexpr (TW) {
+                __builtin_amdgcn_s_barrier();                       // this group's thresholds and target offsets are in the ring
+            } else {
+                philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gid, 0u, a.seed_lo, a.seed_hi, w0);
+                philox4x32_10((uint32_t)((t >> 2) * 64 + lane), sw, gid, 2u, a.seed_lo, a.seed_hi, w2);
+            }
             Q = fetch_adj(t + 1);
-            slot_body(t, P, w0[0], w2[0]);
+            slot_body(integral_constant<int, 0>{}, t, P, w0[0], w2[0]);
             if (t + 1 < slots) {                                    // wave-uniform
                 P = fetch_adj(t + 2);
-                slot_body(t + 1, Q, w0[1], w2[1]);
+                slot_body(integral_constant<int, 1>{}, t + 1, Q, w0[1], w2[1]);
                 if (t + 2 < slots) {
                     Q = fetch_adj(t + 3);
-                    slot_body(t + 2, P, w0[2], w2[2]);
+                    slot_body(integral_constant<int, 2>{}, t + 2, P, w0[2], w2[2]);
                     P = fetch_adj(t + 4);
-                    if (t + 3 < slots) slot_body(t + 3, Q, w0[3], w2[3]);
+                    if (t + 3 < slots) slot_body(integral_constant<int, 3>{}, t + 3, Q, w0[3], w2[3]);
                 }
             }
+            if constexpr (TW) ring_buf ^= 2048u;
         }
         accepted += acc32;
         acc32 = 0;
@@ -321,16 +381,26 @@ __global__ void __launch_bounds__(64, (D == 16 ? 4 : 2)) k_anneal_potts_fast(Ell
 }
 
 template <typename KernelT>
-int launch_potts_fast(KernelT kernel, const EllArgs &a, int km, hipStream_t st)
+int launch_potts_fast(KernelT kernel, const EllArgs &a, int km, bool tw, hipStream_t st)
 {
-    const size_t lds = (size_t)a.slots * 128 + 256;                 // 2 bytes per seat + the cluster sizes
+    const size_t lds = (size_t)a.slots * 128 + 256 + (tw ? 4096 : 0);   // 2 bytes per seat + the cluster sizes (+ the ring)
     if (lds > 160 * 1024) return fail(MI_EUNSUPPORTED, "potts fast kernel: n = %d exceeds the label LDS budget", a.n);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    note_kernel("k_anneal_potts_fast<%d, %d>", a.D, km);
-    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(64), lds, st, a);
+    note_kernel(tw ? "k_anneal_potts_fast<%d, %d, tw>" : "k_anneal_potts_fast<%d, %d>", a.D, km);
+    hipLaunchKernelGGL(kernel, dim3(a.R), dim3(tw ? 128 : 64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return MI_OK;
+}
+
+template <int D, int KM>
+int launch_potts_fast_dk(const EllArgs &a, bool tw, hipStream_t st)
+{
+    const bool um = a.min_size > 0;
+    if (tw) return um ? launch_potts_fast(k_anneal_potts_fast<D, KM, true, true>, a, KM, true, st)
+                      : launch_potts_fast(k_anneal_potts_fast<D, KM, false, true>, a, KM, true, st);
+    return um ? launch_potts_fast(k_anneal_potts_fast<D, KM, true, false>, a, KM, false, st)
+              : launch_potts_fast(k_anneal_potts_fast<D, KM, false, false>, a, KM, false, st);
 }
 
 }  // namespace
@@ -341,18 +411,14 @@ bool mi_potts_fast_eligible(int D, int K, int min_size)
     return (D == 16 || D == 32) && K >= 2 && K <= 16;
 }
 
-// a.adj4 = the packed adjacency with neighbour word = 2 * index (the byte address of the neighbour's 16-bit cell)
-int mi_launch_potts_fast(const EllArgs &a, hipStream_t st)
+// a.adj4 = the packed adjacency with neighbour word = 2 * index (the byte address of the neighbour's 16-bit cell);
+// tw: a threshold wavefront beside the sweeping one (runs of up to 1024 replicas)
+int mi_launch_potts_fast(const EllArgs &a, bool tw, hipStream_t st)
 {
     if (!a.adj4) return fail(MI_EHIP, "potts fast kernel: packed adjacency missing");
     if (!mi_potts_fast_eligible(a.D, a.K, a.min_size)) return fail(MI_EUNSUPPORTED, "potts fast kernel: not built for this model");
-    const bool um = a.min_size > 0;
-    if (a.K <= 8 && !getenv("MI_K3F_KM16")) {
-        if (a.D == 16) return um ? launch_potts_fast(k_anneal_potts_fast<16, 8, true>, a, 8, st) : launch_potts_fast(k_anneal_potts_fast<16, 8, false>, a, 8, st);
-        return um ? launch_potts_fast(k_anneal_potts_fast<32, 8, true>, a, 8, st) : launch_potts_fast(k_anneal_potts_fast<32, 8, false>, a, 8, st);
-    }
-    if (a.D == 16) return um ? launch_potts_fast(k_anneal_potts_fast<16, 16, true>, a, 16, st) : launch_potts_fast(k_anneal_potts_fast<16, 16, false>, a, 16, st);
-    return um ? launch_potts_fast(k_anneal_potts_fast<32, 16, true>, a, 16, st) : launch_potts_fast(k_anneal_potts_fast<32, 16, false>, a, 16, st);
+    if (a.K <= 8 && !getenv("MI_K3F_KM16")) return a.D == 16 ? launch_potts_fast_dk<16, 8>(a, tw, st) : launch_potts_fast_dk<32, 8>(a, tw, st);
+    return a.D == 16 ? launch_potts_fast_dk<16, 16>(a, tw, st) : launch_potts_fast_dk<32, 16>(a, tw, st);
 }
 
 }  // namespace mi_sa_impl

@@ -561,11 +561,12 @@ def test_potts_fast_kernel(K, wide):
     with Problem.potts_csr(pm.rowptr, pm.col, f32(pm.val), c_pair, n, K, lin_offset=pm.lin_offset, order="padded",
                            energy_model=(pm.val, pm.c_pair)) as p:
         assert p.n_dev == N
-        for fast in (0, 2):
+        for fast, tw in ((0, 0), (0, 2), (2, 0)):          # K3f beside its threshold wavefront (few replicas), K3f alone, K3
             p.set_option("k3_fast", fast)
+            p.set_option("k2_tw", tw)
             p.anneal(R, betas, 8, replica_offset=3)
-            assert p.kernel_name() == ("k_anneal_potts_fast<%d, %d>" % (32 if wide else 16, 8 if K <= 8 else 16) if fast == 0
-                                       else "k_anneal_potts<%d>" % (32 if wide else 16)), p.kernel_name()
+            assert p.kernel_name() == ("k_anneal_potts_fast<%d, %d%s>" % (32 if wide else 16, 8 if K <= 8 else 16, ", tw" if tw == 0 else "")
+                                       if fast == 0 else "k_anneal_potts<%d>" % (32 if wide else 16)), p.kernel_name()
             st, en, info = p.fetch()
             assert np.array_equal(st, o_rand[0][:, pos]) and info["accepted"] == int(o_rand[2][1])
             assert info["proposals"] == R * len(betas) * n and np.allclose(en, pm.energies(st), rtol=1e-12)
@@ -592,8 +593,9 @@ def test_potts_fast_kernel(K, wide):
         o_ms = so.potts_csr_philox(rp, cc, vv, c_pair, N, K, R, betas, 8, lin_offset=pm.lin_offset, init=init_ms_dev,
                                    min_size=ms, absent=absent)
         p.set_option("min_cluster_size", ms)
-        for fast in (0, 2):
+        for fast, tw in ((0, 0), (0, 2), (2, 0)):
             p.set_option("k3_fast", fast)
+            p.set_option("k2_tw", tw)
             p.anneal(R, betas, 8, initial_states=init_ms)
             assert p.kernel_name().startswith("k_anneal_potts_fast<" if fast == 0 else "k_anneal_potts<")
             st5, _, info5 = p.fetch()
