@@ -1120,7 +1120,7 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
             // per step beside a threshold wavefront)
             const bool weighted = p->wslot >= 0;
             if (weighted) {
-                if (p->opt_k2_pair != 2 && pair_ok && R > 1024 && one_round(cells + (tw && p->D == 16 ? 4096 : 0), (R + 1) / 2)) choice = 1;
+                if (p->opt_k2_pair != 2 && pair_ok && p->D == 16 && R > 1024 && one_round(cells + (tw ? 4096 : 0), (R + 1) / 2)) choice = 1;
                 else if (p->opt_k2_split != 2 && tw && p->opt_k2_wide != 2 && split_ok &&
                          R <= p->opt_k2_split_max && one_round(cells + 2048, R)) choice = 2;
             } else

@@ -38,7 +38,9 @@ __device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_b
 // 1.5-2), and a third of the instructions of a slot are these thresholds.  A 128-thread workgroup puts its two
 // wavefronts on different SIMDs and every SIMD ends up with two sweeping and two threshold wavefronts
 // (scripts/probe_placement.hip).  Same chain: the thresholds are the same function of (variable, sweep, replica).
-template <int D, bool TW>
+// WGT: the model carries pair-term weights (mi_sa_problem_set_pair_weights; weighted_slot_sweep): a template switch, so
+// that the other models' code is what it was.
+template <int D, bool TW, bool WGT = false>
 __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_pair(EllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // cell of variable i at byte 4 i
@@ -95,7 +97,8 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
 
     // (pair-term weights, mi_sa_problem_set_pair_weights: SA / SB are sum_j w_j x_j; the one slot whose lanes carry weights
     // other than 1 is swept by a serial loop -- weighted_slot_sweep)
-    const int wl = a.wslot >= 0 ? a.wgt[lane] : 0;
+    const int wslot = WGT ? a.wslot : -1;
+    const int wl = wslot >= 0 ? a.wgt[lane] : 0;
     int SA = 0, SB = 0;
     for (int tg = 0; tg * 4 < slots; ++tg) {
         uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
                 xb = real && (wb[c] >> 31);
             }
             cell[i] = (xa ? 0x3c00u : 0u) | (xb ? 0x3c000000u : 0u);
-            if (t == a.wslot) {
+            if (WGT && t == wslot) {
                 SA += (int)wave_sum_i64(xa ? (long long)wl : 0ll);
                 SB += (int)wave_sum_i64(xb ? (long long)wl : 0ll);
             } else {
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
             }
         }
         const uint32_t xiA = (own >> 13) & 1u, xiB = own >> 29;     // 0x3c00 -> 1
-        if (t == a.wslot) {
+        if (WGT && t == wslot) {
             // ---- the slot of the weighted variables: a serial sweep per replica (few lanes, no sparse couplings) ----
             const uint64_t FA = weighted_slot_sweep(gA, thrA, wl, cp, xiA, SA, lane);
             const uint64_t FB = weighted_slot_sweep(gB, thrB, wl, cp, xiB, SB, lane);
@@ -353,7 +356,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
             const int i = t * 64 + lane;
             const bool on = ((cell[i] >> sh) & 0xffffu) != 0u;
             if (i < n) dst[i] = (uint8_t)on;
-            if (t == a.wslot) {
+            if (WGT && t == wslot) {
                 cnt += wave_sum_i64(on ? (long long)wl : 0ll);
                 cnt2 += wave_sum_i64(on ? (long long)wl * wl : 0ll);
             } else {
@@ -409,6 +412,11 @@ int mi_launch_csr_rank1_pair(const EllArgs &a, bool tw, hipStream_t st)
     // the ring costs LDS: beyond 64 slots only seven workgroups (14 replicas) fit a CU, and a run that fills the chip
     // (16 replicas per CU) would take two rounds -- such models keep the kernel without a threshold wavefront
     if (tw && ((size_t)a.slots * 256 + 4096) * 8 > 160 * 1024 && a.R > 2 * 7 * 256) tw = false;
+    if (a.wslot >= 0) {                       // pair-term weights (16 entries per variable)
+        if (a.D != 16) return fail(MI_EUNSUPPORTED, "csr_rank1 pair kernel: pair-term weights at slot-ELL width %d not built", a.D);
+        return tw ? launch_pair(k_anneal_csr_rank1_pair<16, true, true>, a, true, st)
+                  : launch_pair(k_anneal_csr_rank1_pair<16, false, true>, a, false, st);
+    }
     if (a.D == 16 && tw) return launch_pair(k_anneal_csr_rank1_pair<16, true>, a, true, st);
     if (a.D == 16) return launch_pair(k_anneal_csr_rank1_pair<16, false>, a, false, st);
     if (a.D == 32) return launch_pair(k_anneal_csr_rank1_pair<32, false>, a, false, st);

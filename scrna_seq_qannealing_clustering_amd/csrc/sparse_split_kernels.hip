@@ -405,7 +405,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_anneal_csr_rank1_split(EllArgs a
 // two-deep ring in LDS, one s_barrier per group (k_anneal_csr_rank1_pair has the same arrangement): a third of the
 // instructions of a step leave the wavefront whose issue rate bounds the run.  SPB = 1 (TW only): the plain
 // one-slot-per-step sweep, for the 64-seat layouts of small or strongly clustered models.
-template <int D, int SPB, bool TW>
+// WGT: the model carries pair-term weights (mi_sa_problem_set_pair_weights): the sum is sum_j w_j x_j and one slot is swept
+// serially (weighted_slot_sweep) -- a template switch, so that the other models' code is what it was.
+template <int D, int SPB, bool TW, bool WGT = false>
 __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllArgs a)
 {
     static_assert(SPB == 2 || SPB == 4 || (SPB == 1 && TW), "one (with a threshold wavefront), two or four slots per step");
@@ -457,7 +459,8 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
 
     // (pair-term weights, mi_sa_problem_set_pair_weights: S is sum_j w_j x_j; the one slot whose lanes carry weights other
     // than 1 is swept by a serial loop -- weighted_slot_sweep)
-    const int wl = a.wslot >= 0 ? a.wgt[lane] : 0;
+    const int wslot = WGT ? a.wslot : -1;
+    const int wl = wslot >= 0 ? a.wgt[lane] : 0;
     int S = 0;
     for (int t = 0; t < slots; ++t) {
         const int i = t * 64 + lane;
@@ -472,7 +475,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
             x = real && ((c == 0 ? iw[0] : (c == 1 ? iw[1] : (c == 2 ? iw[2] : iw[3]))) >> 31);
         }
         reinterpret_cast<uint32_t *>(lds)[i] = x ? 0x3c00u : 0u;
-        S += t == a.wslot ? (int)wave_sum_i64(x ? (long long)wl : 0ll) : __popcll(__ballot(x));
+        S += (WGT && t == wslot) ? (int)wave_sum_i64(x ? (long long)wl : 0ll) : __popcll(__ballot(x));
     }
 
     constexpr int G = D / 4;
@@ -607,7 +610,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
         for (int j = 0; j < SPB; ++j) {
             const int i = (t0 + j) * 64 + lane;
             const uint32_t xi = own[j] >> 13;                       // 0x3c00 -> 1
-            if (t0 + j == a.wslot) {
+            if (WGT && t0 + j == wslot) {
                 // ---- the slot of the weighted variables: a serial sweep (few lanes, no sparse couplings) ----
                 const uint64_t F = weighted_slot_sweep(gi[j], thr[j], wl, cp, xi, S, lane);
                 acc32 += (uint32_t)__popcll(F);
@@ -674,7 +677,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
         const int i = t * 64 + lane;
         const bool on = cell[i] != 0u;
         if (i < n) dst[i] = (uint8_t)on;
-        if (t == a.wslot) {
+        if (WGT && t == wslot) {
             cnt += wave_sum_i64(on ? (long long)wl : 0ll);
             cnt2 += wave_sum_i64(on ? (long long)wl * wl : 0ll);
         } else {
@@ -737,6 +740,11 @@ int launch_split(KernelT kernel, const EllArgs &a, int nw, hipStream_t st)
 int mi_launch_csr_rank1_wide(const EllArgs &a, int spb, bool tw, hipStream_t st)
 {
     if (!a.adj4) return fail(MI_EHIP, "csr_rank1 wide kernel: packed adjacency missing");
+    if (a.wslot >= 0) {                       // pair-term weights: one slot per step beside a threshold wavefront
+        if (tw && a.D == 16 && spb == 1) return launch_wide(k_anneal_csr_rank1_wide<16, 1, true, true>, a, spb, true, st);
+        if (tw && a.D == 32 && spb == 1) return launch_wide(k_anneal_csr_rank1_wide<32, 1, true, true>, a, spb, true, st);
+        return fail(MI_EUNSUPPORTED, "csr_rank1 wide kernel: a model with pair-term weights runs one slot per step beside a threshold wavefront");
+    }
     if (tw) {
         if (a.D == 16 && spb == 1) return launch_wide(k_anneal_csr_rank1_wide<16, 1, true>, a, spb, true, st);
         if (a.D == 16 && spb == 2) return launch_wide(k_anneal_csr_rank1_wide<16, 2, true>, a, spb, true, st);
