@@ -68,7 +68,7 @@ def _colour(G, nodes, label, lo, hi):
         G.nodes(data=True)[i][label] = col
 
 
-def _solve(G, model, dirs, solver, sampler, num_reads, chain_strength, sampler_kwargs):
+def _solve(G, model, dirs, solver, sampler, num_reads, chain_strength, sampler_kwargs, pending=False):
     name_spec = ''.join([dirs["name"], "_", solver]) if dirs and "name" in dirs else solver
     kw = dict(label=name_spec)
     if solver != "hybrid":                       # :75 / :85 pass the QPU arguments, :57 only the label
@@ -76,20 +76,29 @@ def _solve(G, model, dirs, solver, sampler, num_reads, chain_strength, sampler_k
         if solver == "fixed_embedding":
             kw["return_embedding"] = True
     kw.update(sampler_kwargs or {})
-    return _sampler(sampler).sample_qubo(model, **kw)
+    smp = _sampler(sampler)
+    if pending:                                  # enqueue only (a sampler without the asynchronous entry: None)
+        return smp.sample_qubo_async(model, **kw) if hasattr(smp, "sample_qubo_async") else None
+    return smp.sample_qubo(model, **kw)
 
 
 def clustering_bqm(G, iteration, dirs, solver, gamma_factor, color, terminate_on, size_limit, iter_limit,
-                   chain_strength, sampler=None, sampler_kwargs: Optional[dict] = None, verbose=False, _arrays=None):
+                   chain_strength, sampler=None, sampler_kwargs: Optional[dict] = None, verbose=False, _arrays=None,
+                   _prefetched=None):
     """Recursive 2-way partition with the balanced-cut QUBO (BQM_clustering.py:25-204).  ``_arrays``: the root graph's
-    adjacency as arrays, built by the outermost call and handed down the recursion (models.RootGraphArrays)."""
+    adjacency as arrays, built by the outermost call and handed down the recursion (models.RootGraphArrays).
+    ``_prefetched``: (model, pending sampler call) of this subgraph, enqueued by the parent before it descended into the
+    sibling -- the two halves of a bisection are independent, so the second one anneals while the first one's subtree is
+    worked through (same results, same order of everything the caller sees; a sampler without ``sample_qubo_async`` runs
+    the reference's sequence)."""
     if _arrays is None:
         _arrays = RootGraphArrays.of(G)
-    model = build_bqm_qubo(G, gamma_factor, k=8, arrays=_arrays)     # :29-47
+    model = _prefetched[0] if _prefetched else build_bqm_qubo(G, gamma_factor, k=8, arrays=_arrays)     # :29-47
     if verbose:
         print("gamma: ", model.info["gamma"])
         print("... Running on MI355X ...")
-    response = _solve(G, model, dirs, solver, sampler, 500, chain_strength, sampler_kwargs)   # :52-85
+    response = (_prefetched[1].result() if _prefetched
+                else _solve(G, model, dirs, solver, sampler, 500, chain_strength, sampler_kwargs))   # :52-85
     _print_top(response, verbose)                                     # :88-102
     label = "label" + str(iteration)                                  # :104
     S0, S1 = _split(G, response)                                      # :105-109
@@ -98,10 +107,14 @@ def clustering_bqm(G, iteration, dirs, solver, gamma_factor, color, terminate_on
         print("S1 length: ", len(S1))
 
     def recurse():
-        for part in (S0, S1):
-            clustering_bqm(G.subgraph(part), iteration + 1, dirs, solver, gamma_factor, color + 20,
+        G0, G1 = G.subgraph(S0), G.subgraph(S1)
+        # the second half's call is enqueued before the first half's subtree is worked through (it does not depend on it)
+        m1 = build_bqm_qubo(G1, gamma_factor, k=8, arrays=_arrays)
+        p1 = _solve(G1, m1, dirs, solver, sampler, 500, chain_strength, sampler_kwargs, pending=True)
+        for sub, pre in ((G0, None), (G1, (m1, p1) if p1 is not None else None)):
+            clustering_bqm(sub, iteration + 1, dirs, solver, gamma_factor, color + 20,
                            terminate_on, size_limit, iter_limit, chain_strength, sampler=sampler,
-                           sampler_kwargs=sampler_kwargs, verbose=verbose, _arrays=_arrays)
+                           sampler_kwargs=sampler_kwargs, verbose=verbose, _arrays=_arrays, _prefetched=pre)
 
     if terminate_on == "min_size":                                    # :113-130
         if len(S0) > size_limit and len(S1) > size_limit and iteration < iter_limit:

@@ -50,6 +50,34 @@ def _default_device() -> int:
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+class PendingSampleSet:
+    """A sampler call whose anneal is enqueued on the GPU (``MI355XSampler.sample_qubo_async``); ``result()`` waits for it."""
+
+    def __init__(self, steps):
+        self._steps = steps
+        self._value = None
+        self._done = False
+        self._advance()                                   # runs up to the enqueued anneal (or to the end: an empty model)
+
+    def _advance(self):
+        try:
+            next(self._steps)
+        except StopIteration as stop:
+            self._value, self._done = stop.value, True
+
+    def result(self) -> SampleSet:
+        while not self._done:
+            self._advance()
+        return self._value
+
+    def __del__(self):                                    # an abandoned call still releases its device buffers
+        try:
+            if not self._done:
+                self._steps.close()
+        except Exception:
+            pass
+
+
 class MI355XSampler:
     """Replica-parallel simulated annealing on one MI355X (one wavefront per replica)."""
 
@@ -75,6 +103,15 @@ class MI355XSampler:
         offset = kwargs.pop("offset", 0.0)
         model = Q if isinstance(Q, QuboModel) else qubo_dict_to_model(Q, offset=offset)
         return self._sample_binary(model, "BINARY", kwargs)
+
+    def sample_qubo_async(self, Q, **kwargs) -> "PendingSampleSet":
+        """``sample_qubo`` in two halves: the model is uploaded and the anneal ENQUEUED on the problem's own stream when this
+        returns; ``.result()`` waits for it and builds the SampleSet.  Independent calls overlap on the GPU -- what the
+        two halves of a bisection are (clustering.py prefetches the second half while it descends into the first): with 500
+        reads a call is one wavefront's latency on half of the chip's SIMDs."""
+        offset = kwargs.pop("offset", 0.0)
+        model = Q if isinstance(Q, QuboModel) else qubo_dict_to_model(Q, offset=offset)
+        return PendingSampleSet(self._binary_steps(model, "BINARY", kwargs))
 
     def sample_ising(self, h, J, **kwargs) -> SampleSet:
         bqm = BinaryQuadraticModel.from_ising(h, J, kwargs.pop("offset", 0.0))
@@ -206,6 +243,10 @@ class MI355XSampler:
         return num_reads, arr
 
     def _sample_binary(self, model: QuboModel, vartype: str, kwargs) -> SampleSet:
+        return PendingSampleSet(self._binary_steps(model, vartype, kwargs)).result()
+
+    def _binary_steps(self, model: QuboModel, vartype: str, kwargs):
+        """Generator: everything up to the enqueued anneal, ONE ``yield``, then the fetch and the SampleSet (its return value)."""
         kw, ignored = self._split_kwargs(dict(kwargs))
         t0 = time.perf_counter()
         n = model.num_variables
@@ -247,6 +288,7 @@ class MI355XSampler:
             t1 = time.perf_counter()
             prob.anneal(num_reads, betas, seed, self.replica_offset, init_arr,
                         int(kw.get("resync_interval", 0)))
+            yield None                                # (enqueued: what follows waits for the run)
             states, dev_energy, stats = prob.fetch()
             kernel_ms = prob.kernel_ms()
             t2 = time.perf_counter()
