@@ -152,3 +152,36 @@ def test_main_py_shaped_entry_all_methods(tmp_path, capsys):
     dirs = outputs.define_dirs(256, 5, 15, 15, 0.005, 0.05, "", 1, root=str(tmp_path))
     for key in ("graph_out_bqm", "graph_out_dqm", "graph_out_cqm", "graph_out_pru1", "graph_out_pru2"):
         assert nx.read_gexf(dirs[key]).number_of_nodes() > 0, key
+
+
+def test_bisection_with_the_second_half_enqueued_ahead_equals_the_sequential_run():
+    """clustering_bqm enqueues the second half of every split (MI355XSampler.sample_qubo_async) before it works through the
+    first half's subtree; with a sampler that has no asynchronous entry it runs the reference's sequence.  Same seeds ->
+    the same label attributes on every node at every level, and ``sample_qubo_async(...).result()`` is ``sample_qubo(...)``."""
+    from scrna_seq_qannealing_clustering_amd import MI355XSampler, models
+
+    class SequentialOnly:                                   # hides the asynchronous entry
+        def __init__(self):
+            self._s = MI355XSampler()
+
+        def sample_qubo(self, Q, **kw):
+            return self._s.sample_qubo(Q, **kw)
+
+    fx = load_fixture("blobs")
+    out = []
+    for smp in (MI355XSampler(), SequentialOnly()):
+        G = fx.graph()
+        random.seed(3)
+        clustering.clustering_bqm(G, 1, DIRS, "mi355x", 0.05, 0, "iter_limit", 5, 3, 20, sampler=smp,
+                                  sampler_kwargs=dict(num_reads=64, **FAST))
+        out.append({k: labels(G, k) for k in ("label1", "label2")})
+        assert any(v is not None for v in out[-1]["label2"].values())        # two levels were written
+    assert out[0] == out[1]
+    m = models.build_bqm_qubo(fx.graph(), 0.05)
+    s = MI355XSampler()
+    a = s.sample_qubo_async(m, num_reads=64, **FAST)
+    b = s.sample_qubo_async(m, num_reads=64, num_sweeps=300, seed=12)       # two calls in flight
+    ra, rb, rs = a.result(), b.result(), s.sample_qubo(m, num_reads=64, **FAST)
+    assert np.array_equal(ra.record.sample, rs.record.sample) and np.array_equal(ra.record.energy, rs.record.energy)
+    assert not np.array_equal(rb.record.energy, rs.record.energy) or True    # (another seed: just has to complete)
+    assert a.result() is ra                                                  # idempotent
