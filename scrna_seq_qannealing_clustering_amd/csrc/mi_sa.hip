@@ -1115,19 +1115,29 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
                 return lds_per_wg * (size_t)((wgs + cus - 1) / cus) <= (size_t)160 * 1024;
             };
             const size_t cells = (size_t)p->slots * 256;
+            // K2p: with its threshold wavefront 8 workgroups (16 replicas) fill a CU -- for runs of up to that many; beyond,
+            // the kernel without it holds 16 workgroups per CU (6144 replicas: 4.3e11 against two rounds at 3.5e11).  Models
+            // of up to 4608 variables keep 8 workgroups' cells per CU at any replica count (several rounds if need be);
+            // larger ones take K2p only when one round holds the run.
+            const long pair_wgs = ((long)R + 1) / 2;
+            const long tw_rounds = (pair_wgs + 8 * cus - 1) / (8 * cus);
+            const bool tw_pair = tw && p->D == 16 &&
+                                 ((pair_wgs <= 8 * cus && one_round(cells + 4096, pair_wgs)) ||            // one round, or
+                                  (10 * pair_wgs >= 9 * tw_rounds * 8 * cus && (cells + 4096) * 8 <= (size_t)160 * 1024));   // nearly full ones
+            const bool pair_run = pair_ok && (cells * 8 <= (size_t)150 * 1024 || one_round(cells + (tw_pair ? 4096 : 0), pair_wgs));
             int choice = 0;
             // (a model with pair-term weights: the kernels that sweep its weighted slot are K2, K2p and K2w with one slot
             // per step beside a threshold wavefront)
             const bool weighted = p->wslot >= 0;
             if (weighted) {
-                if (p->opt_k2_pair != 2 && pair_ok && p->D == 16 && R > 1024 && one_round(cells + (tw ? 4096 : 0), (R + 1) / 2)) choice = 1;
+                if (p->opt_k2_pair != 2 && pair_run && p->D == 16 && R > 1024) choice = 1;
                 else if (p->opt_k2_split != 2 && tw && p->opt_k2_wide != 2 && split_ok &&
                          R <= p->opt_k2_split_max && one_round(cells + 2048, R)) choice = 2;
             } else
             if (p->opt_k2_split == 1 && split_ok) choice = 2;
             else if (p->opt_k2_pair == 1 && pair_ok) choice = 1;
             else if (p->opt_k2_split != 2 && split_ok && R <= p->opt_k2_split_max && one_round(cells + 2048, R)) choice = 2;
-            else if (p->opt_k2_pair != 2 && pair_ok && R > 1024 && one_round(cells + (tw && p->D == 16 ? 4096 : 0), (R + 1) / 2)) choice = 1;
+            else if (p->opt_k2_pair != 2 && pair_run && R > 1024) choice = 1;
             if (choice == 2 && weighted) {
                 a.adj4 = p->d_adj4p;                  // (an edge-free layout in wider blocks is one in 64-seat slots too)
                 rc = mi_launch_csr_rank1_wide(a, 1, true, p->stream);
@@ -1143,7 +1153,7 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
                 rc = mi_launch_csr_rank1_split(a, p->k2_free_block / 64, p->stream);
             } else if (choice == 1) {
                 a.adj4 = p->d_adj4p;                  // two replicas per wavefront: half the adjacency traffic per update
-                rc = mi_launch_csr_rank1_pair(a, p->opt_k2_tw != 2 && p->D == 16, p->stream);
+                rc = mi_launch_csr_rank1_pair(a, p->opt_k2_pair == 1 ? (tw && p->D == 16 && pair_wgs <= 8 * cus) : tw_pair, p->stream);
             } else {
                 // K2: every wavefront alone on its SIMD (up to 1024 replicas) -> a threshold wavefront beside it
                 rc = mi_launch_csr_rank1(a, p->stream, tw && R <= 1024 && (p->D == 16 || p->D == 32) && p->k2_state_bytes <= 1);
