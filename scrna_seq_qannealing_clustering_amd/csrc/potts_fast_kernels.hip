@@ -417,7 +417,7 @@ int mi_launch_potts_fast(const EllArgs &a, bool tw, hipStream_t st)
 {
     if (!a.adj4) return fail(MI_EHIP, "potts fast kernel: packed adjacency missing");
     if (!mi_potts_fast_eligible(a.D, a.K, a.min_size)) return fail(MI_EUNSUPPORTED, "potts fast kernel: not built for this model");
-    if (a.K <= 8 && !getenv("MI_K3F_KM16")) return a.D == 16 ? launch_potts_fast_dk<16, 8>(a, tw, st) : launch_potts_fast_dk<32, 8>(a, tw, st);
+    if (a.K <= 8) return a.D == 16 ? launch_potts_fast_dk<16, 8>(a, tw, st) : launch_potts_fast_dk<32, 8>(a, tw, st);
     return a.D == 16 ? launch_potts_fast_dk<16, 16>(a, tw, st) : launch_potts_fast_dk<32, 16>(a, tw, st);
 }
 
