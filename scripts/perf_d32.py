@@ -15,7 +15,7 @@ for k, ord_ in ((5, 15), (8, 30), (12, 60), (20, 120)):
     deg = np.diff(m.rowptr)
     b = models.make_beta_schedule(S, models.default_beta_range(m))
     with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(np.float32), m.lin.astype(np.float32),
-                           float(np.float32(m.c_pair)), order="slots") as p:
+                           float(np.float32(m.c_pair)), order="padded") as p:
         p.anneal(R, b, 1); p.anneal(R, b, 1)
         ms = p.kernel_ms(); _, _, info = p.fetch()
     print("k=%d ord=%d  max degree %d mean %.1f   K2 %.2f ms  %.3e upd/s  acc %.3f" % (
@@ -23,7 +23,7 @@ for k, ord_ in ((5, 15), (8, 30), (12, 60), (20, 120)):
     pm = models.build_dqm_potts(G, 8, 0.005)
     pb = models.make_beta_schedule(S, default_potts_beta_range(pm))
     with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(np.float32), float(np.float32(pm.c_pair)), n, 8,
-                           lin_offset=pm.lin_offset, order="slots") as p:
+                           lin_offset=pm.lin_offset, order="padded") as p:
         p.anneal(R, pb, 1); p.anneal(R, pb, 1)
         ms = p.kernel_ms(); _, _, info = p.fetch()
     print("                                        K3 %.2f ms  %.3e upd/s  acc %.3f" % (

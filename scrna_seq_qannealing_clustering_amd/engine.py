@@ -128,6 +128,12 @@ class Problem:
                 raise ValueError("block must be 64, 128, 256 or 'auto'")
             if block > 64 and clashes:               # no edge-free layout in blocks this wide: the 64-seat layout
                 return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "padded", energy_model)
+            # rows wider than 64 neighbours (untrimmed SNN graphs) run on the runtime-width kernel, whose cost per slot is
+            # the adjacency it streams whether a seat holds a variable or not: a layout that needs many more slots than the
+            # packed one costs more than the serial accept loop it avoids (degree 110: 82 slots against 42, 1.4e10
+            # against 2.6e10 updates/s) -- the packed slot-independent order there
+            if int(np.diff(np.asarray(rowptr)).max(initial=0)) > 64 and nslots * block * 5 > ((len(lin) + 63) // 64) * 64 * 6:
+                return cls.csr_rank1(rowptr, col, val, lin, c_pair, offset, device, "slots", energy_model)
             if block == 128 and nslots % 2:          # (the two-wavefront kernel takes whole groups of four 64-seat slots)
                 nslots += 1
             n_caller, n_dev = len(lin), nslots * block
