@@ -486,11 +486,54 @@ def qubo_dict_to_model(Q: Dict[Tuple[Hashable, Hashable], float], offset: float 
         else:
             order = np.lexsort((sv, su))
             su, sv, sr = su[order], sv[order], sr[order]
+        su, sv, sr, weights = _split_off_pair_weights(n, su, sv, sr, c_pair)
         rowptr, col, val = _csr_from_edges(n, su.astype(np.int32), sv.astype(np.int32), sr)
     else:
+        weights = None
         rowptr, col, val = _csr_from_edges(n, lo.astype(np.int32), hi.astype(np.int32), pb)
     return QuboModel(variables, lin, rowptr, col, val, c_pair=c_pair, offset=float(offset),
-                     info={"kind": "dict"})
+                     info={"kind": "dict"}, weights=weights)
+
+
+def _split_off_pair_weights(n, su, sv, sr, c_pair, max_heavy: int = 64):
+    """What is left of a QUBO after its uniform pair term ``c_pair`` (upper-triangular entries ``sr`` on pairs ``su < sv``)
+    may still hold a few variables coupled to EVERYONE: the slack bits of a squared linear constraint,
+    ``lam (sum x_i + sum c_j t_j - ub)^2`` (bqm.add_linear_inequality_constraint, BQM_clustering.py:373-380), whose pairs
+    carry ``c_pair c_j`` with the cells and ``c_pair c_j c_k`` among themselves.  If the residual of such variables is
+    exactly ``c_pair (a_h - 1)`` on every pair with an ordinary variable and ``c_pair (a_g a_h - 1)`` among them, for
+    integers ``a_h >= 2``, those entries are dropped and returned as pair-term WEIGHTS (QuboModel.weights): the model
+    stays sparse + rank one and runs on the structured kernels.  Otherwise everything is returned unchanged, weights None."""
+    if len(sr) == 0 or n < 4:
+        return su, sv, sr, None
+    deg = np.bincount(su, minlength=n) + np.bincount(sv, minlength=n)
+    heavy = np.flatnonzero(deg >= 0.9 * (n - 1))
+    if len(heavy) == 0 or len(heavy) > max_heavy or n - len(heavy) < 2:
+        return su, sv, sr, None
+    is_h = np.zeros(n, dtype=bool)
+    is_h[heavy] = True
+    n_light = n - len(heavy)
+    hl = is_h[su] != is_h[sv]
+    hh = is_h[su] & is_h[sv]
+    hvar = np.where(is_h[su], su, sv)[hl]
+    r = sr[hl]
+    a = np.ones(n, dtype=np.int64)
+    for h in heavy:
+        rh = r[hvar == h]
+        if len(rh) != n_light:
+            return su, sv, sr, None
+        ah = 1.0 + float(np.median(rh)) / c_pair
+        ai = int(round(ah))
+        if ai < 2 or abs(ah - ai) > 1e-9 * max(1.0, abs(ah)) or np.max(np.abs(rh - c_pair * (ai - 1))) > 1e-9 * abs(c_pair) * ai:
+            return su, sv, sr, None
+        a[h] = ai
+    # among the heavy variables: every pair present with residual c (a_g a_h - 1)
+    if int(np.count_nonzero(hh)) != len(heavy) * (len(heavy) - 1) // 2:
+        return su, sv, sr, None
+    want = c_pair * (a[su[hh]] * a[sv[hh]] - 1)
+    if len(want) and np.max(np.abs(sr[hh] - want)) > 1e-9 * np.max(np.abs(want)):
+        return su, sv, sr, None
+    keep = ~(hl | hh)
+    return su[keep], sv[keep], sr[keep], a
 
 
 def slot_independent_order(rowptr: np.ndarray, col: np.ndarray, slot: int = 64) -> np.ndarray:

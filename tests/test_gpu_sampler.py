@@ -227,3 +227,27 @@ def test_multi_gpu_c_entries_shard_invariance():
     k = int(np.argmin(oen))                                    # the devices' fp64 minima are compared in fp64, ties by id
     assert gid.value == 5 + k and owner.value == (0 if k < 4 else (1 if k < 8 else 2))
     assert e.value == en[k] and np.array_equal(best, st[k])
+
+
+def test_sample_bqm_with_inequality_constraint_runs_structured():
+    """BQM_clustering.py:371-386 as written: from_qubo + add_linear_inequality_constraint + sampler.sample(bqm).  The dense
+    quadratic part is recognised as sparse couplings + a weighted pair term and runs on the CSR kernels; energies are the
+    BQM's own."""
+    from conftest import load_fixture
+    from oracle import model_oracle as mo
+    from scrna_seq_qannealing_clustering_amd import MI355XSampler
+    from scrna_seq_qannealing_clustering_amd.bqm import BinaryQuadraticModel
+    fx = load_fixture("blobs")
+    keep = fx.nodes[:120]
+    ks = set(keep)
+    eu = [(u, v, w) for u, v, w in fx.edges if u in ks and v in ks]
+    bqm = BinaryQuadraticModel.from_qubo(mo.q_bqm_3_cut_only(keep, eu))
+    bqm.add_linear_inequality_constraint([(v, 1) for v in bqm.variables], lb=10, ub=120 / 2.5, lagrange_multiplier=0.9,
+                                         label="c1_constraint")
+    ss = MI355XSampler().sample(bqm, num_reads=128, num_sweeps=400, seed=4)
+    assert ss.info["kernel"] == "csr_rank1"
+    for sample, energy in list(ss.data(fields=["sample", "energy"]))[:5]:
+        assert energy == pytest.approx(bqm.energy(sample), rel=1e-9, abs=1e-7)
+    best = ss.first.sample
+    size = sum(best[v] for v in keep)
+    assert 10 - 1 <= size <= 48 + 1                        # the window holds the best sample's size (penalty 0.9 per unit^2)

@@ -308,3 +308,40 @@ def test_qubo_dict_with_exotic_labels_keeps_them():
     assert np.allclose(m.energies(x), [1.0 + 2.0 + 0.25, -1.0 + 0.5 + 0.25])
     Q2 = {("b", "b"): 1.0, ("a", "b"): 2.0, ("a", "a"): -3.0}
     assert models.qubo_dict_to_model(Q2).variables == ["b", "a"]
+
+
+def test_qubo_dict_with_a_squared_constraint_is_recognised_as_weighted_rank_one():
+    """`clustering_bqm_3` hands its sampler a BQM whose quadratic part is dense after add_linear_inequality_constraint
+    (BQM_clustering.py:371-386).  `sampler.sample(bqm)` sees only the dict: qubo_dict_to_model splits off the uniform pair
+    term AND the slack bits' weights, and ends at the structured model models.add_size_window_penalty builds directly."""
+    fx = load_fixture("blobs")
+    keep = fx.nodes[:60]
+    ks = set(keep)
+    eu = [(u, v, w) for u, v, w in fx.edges if u in ks and v in ks]
+    Q = mo.q_bqm_3_cut_only(keep, eu)
+    bqm = BinaryQuadraticModel.from_qubo(Q)
+    slack = bqm.add_linear_inequality_constraint([(v, 1) for v in bqm.variables], lb=4, ub=60 / 2.5,
+                                                 lagrange_multiplier=0.7, label="c1_constraint")
+    assert sorted(c for _, c in slack) == [1, 2, 4, 5, 8]                    # 20 slack units
+    Qd = {(v, v): b for v, b in bqm.linear.items()}
+    Qd.update(bqm.quadratic)
+    got = models.qubo_dict_to_model(Qd, offset=bqm.offset)
+    assert got._dense is None and got.c_pair == pytest.approx(1.4) and got.weights is not None
+    assert sorted(got.weights[got.weights != 1].tolist()) == [2, 4, 5, 8]
+    assert int(np.diff(got.rowptr).max()) < 30                               # the slack bits kept no sparse couplings
+    assert np.all(np.diff(got.rowptr)[got.weights != 1] == 0)
+    want = models.add_size_window_penalty(models.qubo_dict_to_model(Q), lb=4, ub=60 / 2.5, lagrange_multiplier=0.7)
+    rng = np.random.RandomState(2)
+    order = [got.variables.index(v) for v in want.variables]
+    for _ in range(10):
+        z = rng.randint(0, 2, size=want.num_variables)
+        zg = np.zeros_like(z)
+        zg[order] = z
+        e = bqm.energy(dict(zip(want.variables, z.tolist())))
+        assert got.energies(zg[None, :])[0] == pytest.approx(e, rel=1e-10, abs=1e-9)
+        assert want.energies(z[None, :])[0] == pytest.approx(e, rel=1e-10, abs=1e-9)
+    # a dict that only looks similar (one pair off) stays as it was
+    Qd2 = dict(Qd)
+    k0 = next(k for k in Qd2 if k[0] != k[1] and "slack" in str(k[0]) + str(k[1]) and abs(Qd2[k] - 1.4) > 1.0)   # a weighted pair
+    Qd2[k0] += 0.01
+    assert models.qubo_dict_to_model(Qd2, offset=bqm.offset).weights is None
