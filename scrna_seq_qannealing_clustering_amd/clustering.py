@@ -160,17 +160,20 @@ def clustering_bqm(G, iteration, dirs, solver, gamma_factor, color, terminate_on
 
 
 def clustering_bqm_2(G, iteration, dirs, solver, gamma_factor, color, terminate_on, size_limit, k,
-                     chain_strength, sampler=None, sampler_kwargs: Optional[dict] = None, verbose=False, _arrays=None):
+                     chain_strength, sampler=None, sampler_kwargs: Optional[dict] = None, verbose=False, _arrays=None,
+                     _prefetched=None):
     """Recursive 2-way partition with the linear-penalty QUBO (BQM_clustering.py:206-351).  As in the
-    reference the ``chain_strength`` argument is replaced by mean(w) * mean(deg) * 2 (:220)."""
+    reference the ``chain_strength`` argument is replaced by mean(w) * mean(deg) * 2 (:220).  ``_prefetched``: as in
+    :func:`clustering_bqm`."""
     if _arrays is None:
         _arrays = RootGraphArrays.of(G)
-    model = build_bqm2_qubo(G, gamma_factor, k, arrays=_arrays)      # :210-236
+    model = _prefetched[0] if _prefetched else build_bqm2_qubo(G, gamma_factor, k, arrays=_arrays)      # :210-236
     chain_strength = model.info["chain_strength"]
     if verbose:
         print("gamma: ", model.info["gamma"])
         print("chain_strength: ", chain_strength)
-    response = _solve(G, model, dirs, solver, sampler, 5000, chain_strength, sampler_kwargs)  # :240-273
+    response = (_prefetched[1].result() if _prefetched
+                else _solve(G, model, dirs, solver, sampler, 5000, chain_strength, sampler_kwargs))  # :240-273
     _print_top(response, verbose)
     label = "label" + str(iteration)
     S0, S1 = _split(G, response)
@@ -178,11 +181,14 @@ def clustering_bqm_2(G, iteration, dirs, solver, gamma_factor, color, terminate_
         print("S0 length: ", len(S0))
         print("S1 length: ", len(S1))
 
-    def recurse():
-        for part in (S0, S1):                                         # :317-318, :338-339
-            clustering_bqm_2(G.subgraph(part), iteration + 1, dirs, solver, gamma_factor, color + 20,
+    def recurse():                                                    # :317-318, :338-339
+        G0, G1 = G.subgraph(S0), G.subgraph(S1)
+        m1 = build_bqm2_qubo(G1, gamma_factor, k, arrays=_arrays)     # the second half enqueued ahead (see clustering_bqm)
+        p1 = _solve(G1, m1, dirs, solver, sampler, 5000, m1.info["chain_strength"], sampler_kwargs, pending=True)
+        for sub, pre in ((G0, None), (G1, (m1, p1) if p1 is not None else None)):
+            clustering_bqm_2(sub, iteration + 1, dirs, solver, gamma_factor, color + 20,
                              terminate_on, size_limit, k, chain_strength, sampler=sampler,
-                             sampler_kwargs=sampler_kwargs, verbose=verbose, _arrays=_arrays)
+                             sampler_kwargs=sampler_kwargs, verbose=verbose, _arrays=_arrays, _prefetched=pre)
 
     if terminate_on == "min_size":                                    # :302-318
         for i in S0:                                                  # deterministic colours here (:306, :311)
