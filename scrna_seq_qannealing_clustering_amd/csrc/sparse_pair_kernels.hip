@@ -192,12 +192,31 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
         float gA = __uint_as_float(cur.lin), gB = gA;               // (lanes past n carry lin = +inf: never accepted)
         float thrA = 0.0f, thrB = 0.0f;
         f32x2_t thr2 = {0.0f, 0.0f};
+        // what the accept masks need of the lane's OWN cell (TW: computed under the gathers, see below)
+        uint32_t xiA = 0u, xiB = 0u, sgA = 0u, sgB = 0u;
+        uint64_t XA = 0ull, XB = 0ull;
+        f32x2_t cs = {0.0f, 0.0f}, csf = {0.0f, 0.0f};
+        int ownA = 0, ownB = 0;
+        auto own_terms = [&]() {
+            xiA = (own >> 13) & 1u;                                 // 0x3c00 -> 1
+            xiB = own >> 29;
+            XA = __ballot((own & 0xffffu) != 0u);
+            XB = __ballot((own >> 16) != 0u);
+            sgA = xiA << 31;                                        // dE = x ? -f : f
+            sgB = xiB << 31;
+            cs = f32x2_t{__uint_as_float(__float_as_uint(cp) ^ sgA), __uint_as_float(__float_as_uint(cp) ^ sgB)};
+            ownA = SA - (int)xiA;
+            ownB = SB - (int)xiB;
+            csf = cs * f32x2_t{(float)ownA, (float)ownB};           // the oracle's c * (float)(s - x): one packed multiply
+        };
         K2P_TICK(t_top);
 #pragma unroll
         for (int g0 = 0; g0 < G; g0 += 4) {
             uint32_t word[16];
             // the packed neighbour word IS the LDS byte address of its cell (one wavefront per workgroup, no static LDS)
             if (g0 == 0) asm volatile("ds_read_b32 %0, %1" : "=v"(own) : "v"(i * 4));
+            // (TW: the ring read second, so that "at most 15 reads outstanding" below means the own cell and the thresholds are back)
+            if (g0 == 0 && TW) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(thr2) : "v"(ring_lane + ring_buf), "n"(C * 512));
 #pragma unroll
             for (int k = 0; k < 16; ++k)
 #ifdef MI_K2P_DBG_LINEAR   /* timing only: conflict-free addresses */
@@ -206,11 +225,17 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
                 asm volatile("ds_read_b32 %0, %1" : "=v"(word[k]) : "v"(cur.col[g0 + k / 4][k & 3]));
 #endif
             if (g0 == 0 && TW) {
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(thr2) : "v"(ring_lane + ring_buf), "n"(C * 512));
+                // 18 LDS reads are in flight and they return in order: with at most 15 outstanding the lane's own cell and
+                // the thresholds are here -- everything that depends only on them is computed UNDER the gathers (the
+                // second wait names its results, so it cannot sink below it)
+                asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(own), "+v"(thr2) :: "memory");
+#ifndef MI_K2P_DBG_TERMS_AFTER   /* (timing only: the terms after the full wait, as before) */
+                own_terms();
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(word[0]), "+v"(word[1]), "+v"(word[2]), "+v"(word[3]), "+v"(word[4]), "+v"(word[5]),
                                "+v"(word[6]), "+v"(word[7]), "+v"(word[8]), "+v"(word[9]), "+v"(word[10]), "+v"(word[11]),
-                               "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15]), "+v"(own), "+v"(thr2)
+                               "+v"(word[12]), "+v"(word[13]), "+v"(word[14]), "+v"(word[15]), "+v"(csf)
                              :: "memory");
                 thrA = thr2.x;
                 thrB = thr2.y;
@@ -239,7 +264,11 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
                 gB = __builtin_fmaf(v, half_hi(word[k]), gB);
             }
         }
-        const uint32_t xiA = (own >> 13) & 1u, xiB = own >> 29;     // 0x3c00 -> 1
+#ifdef MI_K2P_DBG_TERMS_AFTER
+        own_terms();
+#else
+        if constexpr (!TW) own_terms();
+#endif
         if (WGT && t == wslot) {
             // ---- the slot of the weighted variables: a serial sweep per replica (few lanes, no sparse couplings) ----
             const uint64_t FA = weighted_slot_sweep(gA, thrA, wl, cp, xiA, SA, lane);
@@ -253,14 +282,10 @@ __global__ void __launch_bounds__(TW ? 128 : 64, TW ? 1 : 2) k_anneal_csr_rank1_
             K2P_TICK(t_rounds);
             return;
         }
-        const uint64_t XA = __ballot((own & 0xffffu) != 0u), XB = __ballot((own >> 16) != 0u);
-        const uint32_t sgA = xiA << 31, sgB = xiB << 31;            // dE = x ? -f : f
         const f32x2_t gs = {__uint_as_float(__float_as_uint(gA) ^ sgA), __uint_as_float(__float_as_uint(gB) ^ sgB)};
-        const f32x2_t cs = {__uint_as_float(__float_as_uint(cp) ^ sgA), __uint_as_float(__float_as_uint(cp) ^ sgB)};
-        const int ownA = SA - (int)xiA, ownB = SB - (int)xiB;
         // accept masks by fixed-point rounds (see k_anneal_csr_rank1): both replicas advance together; the oracle's
         // g + c * (float)(s - x) as one packed multiply and one packed add (no contraction)
-        f32x2_t de = gs + cs * f32x2_t{(float)ownA, (float)ownB};
+        f32x2_t de = gs + csf;
         bool mA = de.x < thrA, mB = de.y < thrB;
         uint64_t AA = __ballot(mA), AB = __ballot(mB);
         K2P_TICK(t_sum);
