@@ -51,7 +51,7 @@ g = snn.build_snn(X, 5, 0.0, 15)
 pm = models.build_dqm_potts(g.to_graph(), 8, 0.005)
 S = 100 if a.quick else 1000
 with Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(f32), float(f32(pm.c_pair)), 2638, 8, lin_offset=pm.lin_offset,
-                       order="slots") as p:
+                       order="padded") as p:
     p.anneal(4096, models.make_beta_schedule(S, default_potts_beta_range(pm)), 1234)
     ms = p.kernel_ms()
     p_kernel3 = p.kernel_name()
@@ -70,7 +70,7 @@ g = snn.build_snn(X, 5, 0.0, 15)
 t_build = time.perf_counter() - t0
 m = models.build_bqm_qubo(g.to_graph(), 0.05)
 S = 20 if a.quick else 200
-with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(f32), m.lin.astype(f32), float(f32(m.c_pair)), order="slots") as p:
+with Problem.csr_rank1(m.rowptr, m.col, m.val.astype(f32), m.lin.astype(f32), float(f32(m.c_pair)), order="padded") as p:
     p.anneal(1024, models.make_beta_schedule(S, models.default_beta_range(m)), 1234)
     ms = p.kernel_ms()
     p_kernel4 = p.kernel_name()
@@ -95,7 +95,7 @@ lo, hi = default_potts_beta_range(pm)
 ladder = np.geomspace(lo * 20, hi / 20, rungs)
 t0 = time.perf_counter()
 prob = Problem.potts_csr(pm.rowptr, pm.col, pm.val.astype(f32), float(f32(pm.c_pair)), n5, 15, lin_offset=pm.lin_offset,
-                         order="slots")
+                         order="padded")
 kernel_ms = [0.0]
 
 
