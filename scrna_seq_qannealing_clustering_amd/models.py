@@ -437,12 +437,23 @@ def qubo_dict_to_model(Q: Dict[Tuple[Hashable, Hashable], float], offset: float 
     try:
         # one pass in C: the 2m labels as an object array, numbered in order of first appearance by pandas' hash table
         # (0.4 s instead of 1.0 s for the two Python-level passes below at m = 3.5 M)
+        import ctypes
         import pandas as pd
         labels = np.fromiter(chain.from_iterable(Q.keys()), dtype=object, count=2 * m)
-        codes, uniques = pd.factorize(labels, use_na_sentinel=False)
-        variables = list(uniques)
-        flat = codes.astype(np.int64, copy=False)
-        if any(v is None or v != v for v in variables):          # (pandas folds None / NaN labels together: the plain walk)
+        # the 2m labels are references to a few thousand objects (the graph's node ids): numbered by OBJECT first -- the
+        # array's PyObject pointers seen as integers, no hashing of 7 M strings -- then the few distinct objects by value
+        ptr = np.ctypeslib.as_array((ctypes.c_ssize_t * (2 * m)).from_address(labels.ctypes.data)) if m else np.zeros(0, dtype=np.intp)
+        codes, uptr = pd.factorize(ptr, use_na_sentinel=False)
+        first = np.full(len(uptr), -1, dtype=np.int64)
+        first[codes[::-1]] = np.arange(2 * m - 1, -1, -1)        # position of every object's first appearance
+        objs = labels[first]
+        index: Dict[Hashable, int] = {}
+        remap = np.empty(len(objs), dtype=np.int64)
+        for k, v in enumerate(objs):                             # (equal labels held by distinct objects fold together here)
+            remap[k] = index.setdefault(v, len(index))
+        variables = list(index)
+        flat = remap[codes] if len(index) != len(objs) else codes.astype(np.int64, copy=False)
+        if any(v is None or v != v for v in variables):          # (None / NaN labels: the plain walk)
             flat = None
     except (ImportError, TypeError, ValueError):
         flat = None
