@@ -297,6 +297,27 @@ def test_error_behaviour():
         assert not lab[:, 2].any() and info["proposals"] == 4 * 6 * 3              # (the engine counts the caller's n)
     with Problem.csr_rank1(rowptr, col, val, np.zeros(3, dtype=np.float32), 0.0) as pb:
         assert lib.mi_sa_problem_set_absent(pb._h, ok.ctypes.data_as(C.POINTER(C.c_uint8))) == -5
+        # pair-term weights: positive integers; the weighted variables have no sparse couplings and share one slot
+        w32 = lambda *a: np.array(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32))
+        assert lib.mi_sa_problem_set_pair_weights(pb._h, w32(3, 1, 1)) == -1       # variable 0 has a coupling
+        assert lib.mi_sa_problem_set_pair_weights(pb._h, w32(1, 1, 0)) == -1       # weights are >= 1
+        assert lib.mi_sa_problem_set_pair_weights(pb._h, None) == -1
+        assert lib.mi_sa_problem_set_pair_weights(pb._h, w32(1, 1, 5)) == -1       # its slot holds variables with couplings
+        _lib.check(lib.mi_sa_problem_set_pair_weights(pb._h, w32(1, 1, 1)))        # all ones: an unweighted model
+    with Problem.potts_csr(rowptr, col, val, 0.1, 3, 2) as pp:
+        assert lib.mi_sa_problem_set_pair_weights(pp._h, np.ones(3, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32))) == -5
+    lin130 = np.zeros(130, dtype=np.float32)
+    with Problem.csr_rank1(np.zeros(131, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32), lin130, 0.1) as pw:
+        w = np.ones(130, dtype=np.int32)
+        w[3], w[100] = 2, 4                                                        # two slots hold weighted variables
+        assert lib.mi_sa_problem_set_pair_weights(pw._h, w.ctypes.data_as(C.POINTER(C.c_int32))) == -1
+        w[3] = 1
+        w[70] = 7                                                                  # slot 1 alone
+        _lib.check(lib.mi_sa_problem_set_pair_weights(pw._h, w.ctypes.data_as(C.POINTER(C.c_int32))))
+        pw.anneal(3, np.geomspace(0.1, 5.0, 6), 3)
+        st, en, _ = pw.fetch()
+        a = w.astype(np.float64)
+        assert np.allclose(en, float(np.float32(0.1)) * 0.5 * ((st @ a) ** 2 - st @ (a * a)), rtol=1e-12, atol=1e-12)   # (the fp32 coefficient: no fp64 energy model was set)
     pos = np.zeros(3, dtype=np.int64)
     ns = C.c_int(0)
     assert lib.mi_sa_plan_slot_layout(rowptr.ctypes.data_as(C.POINTER(C.c_int32)), col.ctypes.data_as(C.POINTER(C.c_int32)),
