@@ -633,6 +633,10 @@ int launch_dense_any(const DenseLaunchCtx &p, const DenseArgs &a, hipStream_t st
     int variant = p.opt_variant;
     if (variant == 0) {
         variant = (a.R >= 2 * kWgWaves && a.num_sweeps > 0) ? 2 : 1;
+        // 128 .. 1024 replicas: a run is one chain's latency whatever serves it (85 ms per 200 sweeps at n = 2638 from 64 to
+        // 2048 replicas), and with at most one wavefront per SIMD the wave-per-replica kernel is the quicker one by 7-10 %
+        // (scripts/perf_dense_few.py); same chain, bit for bit
+        if (variant == 2 && a.R >= 128 && a.R <= 1024) variant = 1;
         // long schedules on sizes K1m is built for: let the device alternate K1m (hot) and K1w (cold)
         if (variant == 2 && NT <= kMaxMfmaNT && a.Qm && p.d_fields && p.opt_chunk_sweeps > 0 &&
             a.num_sweeps > p.opt_chunk_sweeps && p.opt_mfma_permille > 0)

@@ -366,13 +366,20 @@ def test_full_size_scheduled_dense_run_equals_the_workgroup_kernel_alone():
     Qs = np.ascontiguousarray(m.dense_Qs().astype(np.float32))
     betas = models.make_beta_schedule(160, models.default_beta_range(m))
     with Problem.dense(Qs) as p:
-        p.anneal(512, betas, 99, resync_interval=50)
+        p.anneal(2048, betas, 99, resync_interval=50)
         name = p.kernel_name()
         st, en, info = p.fetch()
         p.set_option("mfma_permille", 0)
-        p.anneal(512, betas, 99, resync_interval=50)
+        p.anneal(2048, betas, 99, resync_interval=50)
         name0 = p.kernel_name()
         st0, en0, info0 = p.fetch()
+        # 128 .. 1024 replicas (at most a wavefront per SIMD): the wave-per-replica kernel by the library's own choice --
+        # the same chain, so its 512 replicas are the first 512 of the run above
+        p.set_option("mfma_permille", 600)
+        p.anneal(512, betas, 99, resync_interval=50)
+        assert p.kernel_name().startswith("k_anneal_dense<")
+        st5, en5, _ = p.fetch()
+        assert np.array_equal(st5, st[:512]) and np.array_equal(en5, en[:512])
     assert "dense_mfma" in name and "dense_wg" in name and "dense_mfma" not in name0
     assert np.array_equal(st, st0) and np.array_equal(en, en0)
     assert info["accepted"] == info0["accepted"]
