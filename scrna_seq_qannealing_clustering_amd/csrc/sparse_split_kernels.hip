@@ -533,6 +533,25 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
         }
         // (1) the LDS reads of all SPB slots (at most 16 stay in flight; the issue of the later ones paces itself)
         uint32_t own[SPB], word[SPB][16];
+        constexpr bool PIPE = TW && D == 16 && SPB <= 2;            // (the forms the sampler's layouts run: staged waits below)
+        float thr[SPB];
+        typedef float thr_vec_t __attribute__((ext_vector_type(SPB == 1 ? 2 : SPB)));
+        thr_vec_t tv;                                               // TW: the step's thresholds as they come from the ring
+        if constexpr (PIPE) {
+            // issue order: the own cells, the thresholds, then the gathers position by position across the slots -- LDS reads
+            // return in order, so "at most N outstanding" below names a prefix of this sequence
+#pragma unroll
+            for (int j = 0; j < SPB; ++j)
+                asm volatile("ds_read_b32 %0, %1" : "=v"(own[j]) : "v"(((t0 + j) * 64 + lane) * 4) : "memory");
+            const uint32_t at = ring_lane + ring_buf + (uint32_t)(t0 & 3) * 256u;
+            if constexpr (SPB == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(tv) : "v"(at));
+            else asm volatile("ds_read_b32 %0, %1" : "=v"(tv.x) : "v"(at));
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int j = 0; j < SPB; ++j)
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(word[j][k]) : "v"(cur.s[j].col[k / 4][k & 3]));
+        } else {
 #pragma unroll
         for (int j = 0; j < SPB; ++j) {
             asm volatile("ds_read_b32 %0, %1" : "=v"(own[j]) : "v"(((t0 + j) * 64 + lane) * 4) : "memory");
@@ -540,10 +559,10 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
             for (int k = 0; k < 16; ++k)
                 asm volatile("ds_read_b32 %0, %1" : "=v"(word[j][k]) : "v"(cur.s[j].col[k / 4][k & 3]));
         }
-        float thr[SPB];
-        typedef float thr_vec_t __attribute__((ext_vector_type(SPB == 1 ? 2 : SPB)));
-        thr_vec_t tv;                                               // TW: the step's thresholds as they come from the ring
-        if constexpr (TW) {
+        }
+        if constexpr (PIPE) {
+            // (2) (the thresholds were requested with the own cells)
+        } else if constexpr (TW) {
             // (2) the SPB thresholds of the step from the ring: one read, waited for with the gathers (below)
             const uint32_t at = ring_lane + ring_buf + (uint32_t)(t0 & 3) * 256u;
             if constexpr (SPB == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(tv) : "v"(at));
@@ -567,15 +586,65 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
 #pragma unroll
             for (int k = 0; k < (10 * SPB) / 4; ++k) nx.round();    // (a group lasts 4 / SPB steps: never past ten rounds)
         }
+        // (3) the field sums: SPB independent chains
+        float gi[SPB];
+#pragma unroll
+        for (int j = 0; j < SPB; ++j) gi[j] = __uint_as_float(cur.s[j].lin);
+        auto fma_k = [&](int j, int k) {
+            const half_t hx = __builtin_bit_cast(half_t, (uint16_t)word[j][k]);
+            gi[j] = __builtin_fmaf(__uint_as_float(cur.s[j].val[k / 4][k & 3]), (float)hx, gi[j]);   // fma(val, x, g)
+        };
+        if constexpr (PIPE && SPB == 2) {
+            // 35 reads in flight: own 0, own 1, thresholds, then w[0][k], w[1][k] for k = 0 .. 15.  A wavefront alone on its
+            // SIMD is parked on s_waitcnt half of its time if it waits for all of them (profiles/r03_k2w_binding.json): the two
+            // fma chains advance in three stages behind counted waits -- at most 15 outstanding: k < 8 of both slots are back;
+            // at most 7: k < 12; none: all -- each wait naming what the stage before it produced, so nothing sinks below it
+            asm volatile("s_waitcnt lgkmcnt(15)"
+                         : "+v"(word[0][0]), "+v"(word[0][1]), "+v"(word[0][2]), "+v"(word[0][3]), "+v"(word[0][4]), "+v"(word[0][5]),
+                           "+v"(word[0][6]), "+v"(word[0][7]), "+v"(word[1][0]), "+v"(word[1][1]), "+v"(word[1][2]), "+v"(word[1][3]),
+                           "+v"(word[1][4]), "+v"(word[1][5]), "+v"(word[1][6]), "+v"(word[1][7]), "+v"(own[0]), "+v"(own[1]), "+v"(tv)
+                         :: "memory");
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { fma_k(0, k); fma_k(1, k); }
+            asm volatile("s_waitcnt lgkmcnt(7)"
+                         : "+v"(word[0][8]), "+v"(word[0][9]), "+v"(word[0][10]), "+v"(word[0][11]), "+v"(word[1][8]), "+v"(word[1][9]),
+                           "+v"(word[1][10]), "+v"(word[1][11]), "+v"(gi[0]), "+v"(gi[1])
+                         :: "memory");
+#pragma unroll
+            for (int k = 8; k < 12; ++k) { fma_k(0, k); fma_k(1, k); }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(word[0][12]), "+v"(word[0][13]), "+v"(word[0][14]), "+v"(word[0][15]), "+v"(word[1][12]), "+v"(word[1][13]),
+                           "+v"(word[1][14]), "+v"(word[1][15]), "+v"(gi[0]), "+v"(gi[1])
+                         :: "memory");
+#pragma unroll
+            for (int k = 12; k < 16; ++k) { fma_k(0, k); fma_k(1, k); }
+            thr[0] = tv[0];
+            thr[1] = tv[1];
+        } else if constexpr (PIPE && SPB == 1) {
+            // one slot per step: 18 reads in flight (own, threshold, 16 gathers), the fma chain in four stages of four
+            asm volatile("s_waitcnt lgkmcnt(12)"
+                         : "+v"(word[0][0]), "+v"(word[0][1]), "+v"(word[0][2]), "+v"(word[0][3]), "+v"(own[0]), "+v"(tv) :: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fma_k(0, k);
+            asm volatile("s_waitcnt lgkmcnt(8)"
+                         : "+v"(word[0][4]), "+v"(word[0][5]), "+v"(word[0][6]), "+v"(word[0][7]), "+v"(gi[0]) :: "memory");
+#pragma unroll
+            for (int k = 4; k < 8; ++k) fma_k(0, k);
+            asm volatile("s_waitcnt lgkmcnt(4)"
+                         : "+v"(word[0][8]), "+v"(word[0][9]), "+v"(word[0][10]), "+v"(word[0][11]), "+v"(gi[0]) :: "memory");
+#pragma unroll
+            for (int k = 8; k < 12; ++k) fma_k(0, k);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(word[0][12]), "+v"(word[0][13]), "+v"(word[0][14]), "+v"(word[0][15]), "+v"(gi[0]) :: "memory");
+#pragma unroll
+            for (int k = 12; k < 16; ++k) fma_k(0, k);
+            thr[0] = tv[0];
+        } else {
         if constexpr (TW) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv) :: "memory");
 #pragma unroll
             for (int j = 0; j < SPB; ++j) thr[j] = tv[j];
         }
-        // (3) the field sums: SPB independent chains
-        float gi[SPB];
-#pragma unroll
-        for (int j = 0; j < SPB; ++j) gi[j] = __uint_as_float(cur.s[j].lin);
 #pragma unroll
         for (int g0 = 0; g0 < G; g0 += 4) {
             if (g0 > 0) {
@@ -603,6 +672,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, 1) k_anneal_csr_rank1_wide(EllA
                     const half_t hx = __builtin_bit_cast(half_t, (uint16_t)word[j][k]);
                     gi[j] = __builtin_fmaf(__uint_as_float(cur.s[j].val[g0 + k / 4][k & 3]), (float)hx, gi[j]);   // fma(val, x, g)
                 }
+        }
         }
         // (4) the accept masks, slot after slot (k_anneal_csr_rank1's rounds); the block holds no edge, so a later slot's
         // field sum does not see an earlier slot's flips -- only the sum does

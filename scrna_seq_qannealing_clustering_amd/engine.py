@@ -18,7 +18,7 @@ def layout_block_for(n: int, num_reads: int, max_degree: int = 16):
     every wavefront has a SIMD to itself and a run takes (steps per sweep) x (one wavefront's time per step):
     ``Problem.csr_rank1`` then plans the 64-seat AND the 128-seat layout and takes the wider one when it needs few
     enough blocks -- one wavefront sweeps such a block per step (K2w, csrc/sparse_split_kernels.hip: with the thresholds
-    coming from the workgroup's second wavefront a two-slot step takes 1.77 times a one-slot step) -- which large sparse
+    coming from the workgroup's second wavefront a two-slot step takes 1.86 times a one-slot step) -- which large sparse
     graphs do (n = 2638: 22 blocks against 42 slots) and small or clustered ones, whose block count is set by the
     colours they need, do not."""
     if num_reads > 1024 or max_degree > 32 or n > 16384 or n < 1024:     # (below ~1000 variables the colours decide)
@@ -27,8 +27,9 @@ def layout_block_for(n: int, num_reads: int, max_degree: int = 16):
 
 
 # a two-slot step of the wide kernel against a one-slot step (MI355X, a wavefront alone on its SIMD, thresholds from the
-# second wavefront of its workgroup: 464 ns per 128-seat block, 262 ns per 64-seat slot at n = 2638, 500 reads)
-_WIDE_STEP_RATIO = 464.0 / 262.0
+# second wavefront of its workgroup, field sums staged behind counted LDS waits: 439 ns per 128-seat block, 236 ns per
+# 64-seat slot at n = 2638, 500 reads)
+_WIDE_STEP_RATIO = 439.0 / 236.0
 
 
 def _ptr(a, ctype):
