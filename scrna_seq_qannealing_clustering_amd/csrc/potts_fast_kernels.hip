@@ -184,6 +184,59 @@ __global__ void __launch_bounds__(TW ? 128 : 64, (TW ? 2 : (D == 16 ? 4 : 2))) k
         float thr = 0.0f;
         u32x2 tw2 = {0u, 0u};                                       // TW: (threshold bits, target offset) from the ring
         uint32_t la = 0u, lb = 0u, tlo = 0u, thi = 0u;
+        int na0, nb0;                                               // sizes of the lane's two clusters
+        auto proposal = [&](uint32_t rem) {
+            // a = the lane's label, b = (a + 1 + word mod (K - 1)) mod K; and the lookup table of sigma
+            la = dec_label<KM>(own);
+            lb = la + 1u + rem;                                     // in [1, 2K - 2]
+            lb = lb >= (uint32_t)K ? lb - (uint32_t)K : lb;
+            if constexpr (KM == 8) {
+                const uint64_t tbl = (0xc0ull << (la * 8u)) | (0x40ull << (lb * 8u));
+                tlo = (uint32_t)tbl;
+                thi = (uint32_t)(tbl >> 32);
+            } else {
+                tlo = (3u << (la * 2u)) | (1u << (lb * 2u));
+            }
+        };
+        auto fma_k = [&](int g0, int k) {
+            const float v = __uint_as_float(cur.val[g0 + k / 4][k & 3]);
+            if constexpr (KM == 8) {
+                const uint32_t pk = __builtin_amdgcn_perm(thi, tlo, sel[k]);                     // low half: fp16 +2, -2 or 0
+                hd = __builtin_fmaf(v, (float)__builtin_bit_cast(half_t, (uint16_t)pk), hd);
+            } else {
+                hd = __builtin_fmaf(v, (float)(int)__builtin_amdgcn_sbfe((int)tlo, sel[k], 2u), hd);   // +1, -1 or 0 (the builtin's result type is unsigned)
+            }
+        };
+        if constexpr (TW && G == 4) {
+            // A wavefront alone on its SIMD (runs of up to 1024 replicas) is parked on s_waitcnt half of its time if it waits
+            // for all its LDS reads at once: the own cell and the ring entry go FIRST, the proposal and its table are worked
+            // out while the gathers arrive, the two cluster sizes are requested then, and the fma chain follows the gathers
+            // in stages of four behind counted waits (LDS reads return in order; every wait names what the stage before it
+            // produced, so nothing sinks below it)
+            asm volatile("ds_read_u16 %0, %1" : "=v"(own) : "v"(i * 2));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(tw2) : "v"(ring_lane + ring_buf), "n"(C * 512));
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                asm volatile("ds_read_u16 %0, %1" : "=v"(sel[k]) : "v"(cur.col[k / 4][k & 3]));
+            asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(own), "+v"(tw2), "+v"(sel[0]) :: "memory");        // 18 issued: the 3 oldest are back
+            thr = __uint_as_float(tw2.x);
+            if (cur.meta >> 31) thr = -INFINITY;                    // nobody sits here
+            proposal(tw2.y);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(na0) : "v"(cnt_base + la * 4u));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(nb0) : "v"(cnt_base + lb * 4u));
+            asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(sel[1]), "+v"(sel[2]), "+v"(sel[3]), "+v"(tlo), "+v"(thi) :: "memory");   // 20 issued: 6 back
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fma_k(0, k);
+            asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(sel[4]), "+v"(sel[5]), "+v"(sel[6]), "+v"(sel[7]), "+v"(hd) :: "memory");
+#pragma unroll
+            for (int k = 4; k < 8; ++k) fma_k(0, k);
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(sel[8]), "+v"(sel[9]), "+v"(sel[10]), "+v"(sel[11]), "+v"(hd) :: "memory");
+#pragma unroll
+            for (int k = 8; k < 12; ++k) fma_k(0, k);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(sel[12]), "+v"(sel[13]), "+v"(sel[14]), "+v"(sel[15]), "+v"(hd) :: "memory");
+#pragma unroll
+            for (int k = 12; k < 16; ++k) fma_k(0, k);
+        } else {
 #pragma unroll
         for (int g0 = 0; g0 < G; g0 += 4) {
             if (g0 == 0) asm volatile("ds_read_u16 %0, %1" : "=v"(own) : "v"(i * 2));
@@ -218,17 +271,7 @@ __global__ void __launch_bounds__(TW ? 128 : 64, (TW ? 2 : (D == 16 ? 4 : 2))) k
                     rem = w2c - __umulhi(w2c, magic) * dK;          // in [0, 2 dK)
                     rem = rem >= dK ? rem - dK : rem;
                 }
-                // the proposal: a = the lane's label, b = (a + 1 + word mod (K - 1)) mod K; and the lookup table of sigma
-                la = dec_label<KM>(own);
-                lb = la + 1u + rem;                                 // in [1, 2K - 2]
-                lb = lb >= (uint32_t)K ? lb - (uint32_t)K : lb;
-                if constexpr (KM == 8) {
-                    const uint64_t tbl = (0xc0ull << (la * 8u)) | (0x40ull << (lb * 8u));
-                    tlo = (uint32_t)tbl;
-                    thi = (uint32_t)(tbl >> 32);
-                } else {
-                    tlo = (3u << (la * 2u)) | (1u << (lb * 2u));
-                }
+                proposal(rem);
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(sel[0]), "+v"(sel[1]), "+v"(sel[2]), "+v"(sel[3]), "+v"(sel[4]), "+v"(sel[5]),
@@ -237,20 +280,12 @@ __global__ void __launch_bounds__(TW ? 128 : 64, (TW ? 2 : (D == 16 ? 4 : 2))) k
                              :: "memory");
             }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float v = __uint_as_float(cur.val[g0 + k / 4][k & 3]);
-                if constexpr (KM == 8) {
-                    const uint32_t pk = __builtin_amdgcn_perm(thi, tlo, sel[k]);                 // low half: fp16 +2, -2 or 0
-                    hd = __builtin_fmaf(v, (float)__builtin_bit_cast(half_t, (uint16_t)pk), hd);
-                } else {
-                    hd = __builtin_fmaf(v, (float)(int)__builtin_amdgcn_sbfe((int)tlo, sel[k], 2u), hd);   // +1, -1 or 0 (the builtin's result type is unsigned)
-                }
-            }
+            for (int k = 0; k < 16; ++k) fma_k(g0, k);
         }
         // sizes of the lane's two clusters (the atomics of the previous slot are ordered before these reads)
-        int na0, nb0;
         asm volatile("ds_read_b32 %0, %1" : "=v"(na0) : "v"(cnt_base + la * 4u));
         asm volatile("ds_read_b32 %0, %1" : "=v"(nb0) : "v"(cnt_base + lb * 4u));
+        }
         // a mover's contribution to the packed per-cluster bytes: 1 everywhere, +1 at its target, -1 at its source (0, 1
         // or 2: no borrow between bytes, sums <= 128); byte q of the inclusive scan at lane i = (i + 1) + net change of
         // cluster q by the movers up to and including i.  K <= 8: one 64-bit value (K <= 4: its low dword), else two.
