@@ -42,7 +42,8 @@
 #endif
 
 // diagnostic timing builds (-DMI_K1M_DEBUG; results are wrong): DenseArgs::debug bit0 = no ring DMA, bit2 = no
-// decision chain, bit3 = no MFMAs.  -DMI_K1M_TICKS: s_memtime phase counters in stats[4..12].
+// decision chain, bit3 = no MFMAs.  -DMI_K1M_TICKS: s_memtime phase counters of the wave `debug >> 8` in stats[4..13]
+// (per phase g: the rendezvous; operand reads; MFMA issue; what follows them -- printed by scripts/perf_k1m.py).
 #ifdef MI_K1M_DEBUG
 #define K1M_DBG(bit) ((a.debug & (bit)) != 0)
 #else
@@ -425,7 +426,9 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
                 }
                 // (the copy of the owner's tile for DIAG(nb): as it is BEFORE this block's rows go in)
                 if constexpr (g == 0) { if ((own_chain)) dump_tile(nb >> 4); }
+                K1M_TICK(t_thr);
                 if (mfma_on) run_mfmas();
+                K1M_TICK(t_body[g]);
                 // everything else AFTER the MFMAs are queued: the stream's bookkeeping (loader waves) and the owner's
                 // piece of DIAG(nb) run under the matrix pipe, not in front of it
                 if ((loader)) issue_unit();                             // into the slot the previous unit vacated
@@ -454,6 +457,7 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
                 }
                 cur_slot = uni((cur_slot + 1 == C::U) ? 0 : cur_slot + 1);
                 processed = uni(processed + 1);
+                K1M_TICK(t_diag);
             });
             gb = uni(gb + 1);
         }
