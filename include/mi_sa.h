@@ -100,7 +100,9 @@ int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases
  * minimum size is set; 2 never), "xl_batched" (dense, n > 4096: 0 auto = all replicas together on the matrix cores from 256
  * replicas or n = 16384 up, 1 always, 2 a workgroup per replica), "xl_chain" (0 auto = the decisions and small passes of a group of eight blocks as one launch up to 512
  * replicas, 1 = one launch per block, 2 = fused always), "xl_chunk" (8) / "xl_cold_permille" (20): that batched kernel
- * hands a cooling run over to the per-replica kernel when a chunk of sweeps accepted less than this share.
+ * hands a cooling run over to the per-replica kernel when a chunk of sweeps accepted less than this share; the decision
+ * is taken per chunk on the host, by a worker thread of the problem ("xl_async" 1, the default: mi_sa_anneal returns at
+ * once and the next call on the problem joins the worker, reporting its error if it had one; 0: in the calling thread).
  * One MODEL switch: "min_cluster_size" (Potts problems, default 0) -- every cluster keeps at least that many
  * members: a move out of a cluster holding exactly that many is rejected whatever its energy change.  This
  * is the `sum_i v[i][j] >= 20` constraint of the reference's CQM (CQM_clustering.py:46-48) as a hard

@@ -24,6 +24,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -170,6 +171,10 @@ struct mi_sa_problem {
     int opt_xl_chain = 0;                    // K1g, chain of a group of blocks: 0 auto (fused up to 512 replicas), 1 a DIAG and a small pass per block, 2 fused
     int opt_xl_chunk = 8;                    // K1g: sweeps per chunk of a cooling run (the hand-over to K1x is decided per chunk)
     int opt_xl_cold_permille = 20;           // hand the rest of the run to K1x when a chunk accepted less than this share (0 = never)
+    int opt_xl_async = 1;                    // that cooling run is driven by a worker thread: mi_sa_anneal returns at once (0 = in the caller)
+    std::thread worker;                      // joined by the next call on this problem (settle)
+    int worker_rc = MI_OK;
+    std::string worker_err, worker_kernel;
     int xl_chunks = 0;
     // structured kinds (slot-ELL)
     int slots = 0, D = 0;
@@ -299,6 +304,22 @@ constexpr int kMaxDenseN = 64 * 64;        // register-per-wave kernels (K1, K1w
 constexpr int kMaxDenseXlN = 16 * 4096;    // workgroup-per-replica kernel (K1x)
 
 }  // namespace
+
+// A cooling run on the batched large-model kernels decides its hand-over per chunk on the host (anneal_ex_impl), in a worker
+// thread of the problem.  Every entry point that takes the problem joins that thread first; its error becomes the error of
+// the joining call.
+static int settle(mi_sa_problem *p)
+{
+    if (!p || !p->worker.joinable()) return MI_OK;
+    p->worker.join();
+    p->last_kernel = p->worker_kernel;
+    if (p->worker_rc) {
+        const int rc = p->worker_rc;
+        p->worker_rc = MI_OK;
+        return fail(rc, "%s", p->worker_err.c_str());
+    }
+    return MI_OK;
+}
 
 extern "C" {
 
@@ -795,6 +816,7 @@ int mi_sa_problem_create_potts_csr_f32(const int32_t *rowptr, const int32_t *col
 
 static int set_energy_model_impl(mi_sa_problem *p, const double *val, const double *lin, double c_pair)
 {
+    if (const int rc_w = settle(p)) return rc_w;
     if (!p) return fail(MI_EINVAL, "NULL problem");
     if (p->kind != MI_KIND_CSR_RANK1 && p->kind != MI_KIND_POTTS_CSR)
         return fail(MI_EUNSUPPORTED, "an fp64 energy model is defined for the structured kinds only");
@@ -820,6 +842,7 @@ static int set_energy_model_impl(mi_sa_problem *p, const double *val, const doub
 int mi_sa_problem_set_absent(mi_sa_problem *p, const uint8_t *absent)
 {
     if (!p || !absent) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     if (p->kind != MI_KIND_POTTS_CSR)
         return fail(MI_EUNSUPPORTED, "holes of a Potts model only (a binary CSR model marks them by lin = +inf)");
     return guarded([&]() -> int {
@@ -838,6 +861,7 @@ int mi_sa_problem_set_absent(mi_sa_problem *p, const uint8_t *absent)
 int mi_sa_problem_set_pair_weights(mi_sa_problem *p, const int32_t *weights)
 {
     if (!p || !weights) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     if (p->kind != MI_KIND_CSR_RANK1)
         return fail(MI_EUNSUPPORTED, "pair-term weights: structured binary (CSR + uniform pair) problems only");
     return guarded([&]() -> int {
@@ -887,6 +911,7 @@ int mi_sa_problem_set_energy_model_f64(mi_sa_problem *p, const double *val, cons
 int mi_sa_problem_destroy(mi_sa_problem *p)
 {
     if (!p) return MI_OK;
+    (void)settle(p);
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     void *bufs[] = {p->d_wgt, p->d_xg, p->d_pt_rung, p->d_pt_betas, p->d_pt_energy, p->d_pt_ladder, p->d_pt_temps, p->d_pt_stats, p->d_adj4p, p->d_ell_val64, p->d_lin64, p->d_Q2xl, p->d_diagxl, p->d_rows, p->d_meta, p->d_adj4, p->d_slot_flags, p->d_Qm, p->d_fields, p->d_ctrl, p->d_ell_col, p->d_ell_val, p->d_lin, p->d_pace, p->d_Qp, p->d_Qs, p->d_temps, p->d_init, p->d_states, p->d_energy, p->d_stats};
@@ -912,6 +937,7 @@ int mi_sa_problem_info(const mi_sa_problem *p, int *kind, int *n, int *num_cases
 int mi_sa_debug_stats(mi_sa_problem *p, uint64_t *out, int words)
 {
     if (!p || !out) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (words > 16) words = 16;
@@ -927,6 +953,7 @@ int mi_sa_debug_stats(mi_sa_problem *p, uint64_t *out, int words)
 int mi_sa_debug_pace(mi_sa_problem *p, unsigned int *out, int words)
 {
     if (!p || !out) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (words > kPaceWords) words = kPaceWords;
@@ -937,11 +964,13 @@ int mi_sa_debug_pace(mi_sa_problem *p, unsigned int *out, int words)
 int mi_sa_set_option(mi_sa_problem *p, const char *key, long value)
 {
     if (!p || !key) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     if (!strcmp(key, "pace")) { p->opt_pace = value != 0; return MI_OK; }
     if (!strcmp(key, "xl_batched") && value >= 0 && value <= 2) { p->opt_xl_batched = (int)value; return MI_OK; }
     if (!strcmp(key, "xl_chunk") && value >= 1) { p->opt_xl_chunk = (int)value; return MI_OK; }
     if (!strcmp(key, "xl_chain") && value >= 0 && value <= 2) { p->opt_xl_chain = (int)value; return MI_OK; }
     if (!strcmp(key, "xl_cold_permille") && value >= 0 && value <= 1000) { p->opt_xl_cold_permille = (int)value; return MI_OK; }
+    if (!strcmp(key, "xl_async") && value >= 0 && value <= 1) { p->opt_xl_async = (int)value; return MI_OK; }
     if (!strcmp(key, "mfma_permille") && value >= 0 && value <= 1000) { p->opt_mfma_permille = (int)value; return MI_OK; }
     if (!strcmp(key, "chunk_sweeps") && value >= 0) { p->opt_chunk_sweeps = (int)value; return MI_OK; }
     if (!strcmp(key, "ondemand_permille") && value >= 0 && value <= 1000) { p->opt_ondemand_permille = (int)value; return MI_OK; }
@@ -967,6 +996,7 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
                           const double *betas, uint64_t seed, const void *init, int resync_interval,
                           uint32_t sweep_offset, uint32_t flags)
 {
+    if (const int rc_w = settle(p)) return rc_w;
     const bool cont = (flags & MI_F_CONTINUE) != 0, resident = (flags & MI_F_TEMPS_RESIDENT) != 0;
     const bool per_replica = (flags & MI_F_BETA_PER_REPLICA) != 0 || resident;
     const int num_betas = per_replica ? R : num_sweeps;
@@ -1034,31 +1064,55 @@ static int anneal_ex_impl(mi_sa_problem *p, int R, uint32_t replica_offset, int 
             // K1g costs the same hot or cold (two launches per 64 rows whether anything flips or not); K1x costs per
             // accepted flip.  Along a cooling schedule: K1g in chunks of sweeps while the chunks accept enough, then
             // K1x for the rest, continuing from K1g's states AND cached fields (same chain, bit for bit).  The hand-over
-            // is decided on the host: this call waits for the hot chunks.
-            int s0 = 0;
-            while (!rc && s0 < num_sweeps) {
-                const int len = num_sweeps - s0 < p->opt_xl_chunk ? num_sweeps - s0 : p->opt_xl_chunk;
-                DenseXlArgs b = a;
-                b.num_sweeps = len; b.temps = a.temps + s0; b.sweep_offset = a.sweep_offset + (uint32_t)s0;
-                unsigned long long before = 0, after = 0;
-                HIP_TRY(hipMemcpyAsync(&before, p->d_stats + 1, sizeof before, hipMemcpyDeviceToHost, p->stream));
-                rc = mi_launch_dense_xg(b, p->xl_chunks, p->d_xg, p->stream, (s0 == 0 ? 1 : 0) | 2);
-                if (rc) break;
-                s0 += len;
-                if (s0 >= num_sweeps) break;
-                HIP_TRY(hipMemcpyAsync(&after, p->d_stats + 1, sizeof after, hipMemcpyDeviceToHost, p->stream));
-                HIP_TRY(hipStreamSynchronize(p->stream));
-                const double share = (double)(after - before) / ((double)R * (double)p->n * (double)len);
-                if (share * 1000.0 < (double)p->opt_xl_cold_permille) {
-                    DenseXlArgs c = a;
-                    c.num_sweeps = num_sweeps - s0; c.temps = a.temps + s0; c.sweep_offset = a.sweep_offset + (uint32_t)s0;
-                    c.init = (const uint8_t *)p->d_states;             // written by the chunk that just ended
-                    c.fields_in = mi_dense_xg_fields(p->d_xg);
-                    c.fin_ncols = (p->n + 255) / 256 * 256;
-                    rc = mi_launch_dense_xl(c, p->xl_chunks, p->stream);
-                    break;
+            // is decided on the host, chunk by chunk -- a device-side mode word as on the n <= 4096 scheduler would need
+            // every chunk's launches enqueued in advance (1600 per sweep at n = 50 000, each an empty launch once the
+            // run has gone cold: seconds) -- so a worker thread of the problem waits for the chunks and this call
+            // returns at once, like every other anneal; the next call on the problem joins it (settle).
+            auto cooling_run = [p, a, num_sweeps, R]() -> int {
+                HIP_TRY(hipSetDevice(p->device));
+                int rc = MI_OK, s0 = 0;
+                while (!rc && s0 < num_sweeps) {
+                    const int len = num_sweeps - s0 < p->opt_xl_chunk ? num_sweeps - s0 : p->opt_xl_chunk;
+                    DenseXlArgs b = a;
+                    b.num_sweeps = len; b.temps = a.temps + s0; b.sweep_offset = a.sweep_offset + (uint32_t)s0;
+                    unsigned long long before = 0, after = 0;
+                    HIP_TRY(hipMemcpyAsync(&before, p->d_stats + 1, sizeof before, hipMemcpyDeviceToHost, p->stream));
+                    rc = mi_launch_dense_xg(b, p->xl_chunks, p->d_xg, p->stream, (s0 == 0 ? 1 : 0) | 2);
+                    if (rc) break;
+                    s0 += len;
+                    if (s0 >= num_sweeps) break;
+                    HIP_TRY(hipMemcpyAsync(&after, p->d_stats + 1, sizeof after, hipMemcpyDeviceToHost, p->stream));
+                    HIP_TRY(hipStreamSynchronize(p->stream));
+                    const double share = (double)(after - before) / ((double)R * (double)p->n * (double)len);
+                    if (share * 1000.0 < (double)p->opt_xl_cold_permille) {
+                        DenseXlArgs c = a;
+                        c.num_sweeps = num_sweeps - s0; c.temps = a.temps + s0; c.sweep_offset = a.sweep_offset + (uint32_t)s0;
+                        c.init = (const uint8_t *)p->d_states;             // written by the chunk that just ended
+                        c.fields_in = mi_dense_xg_fields(p->d_xg);
+                        c.fin_ncols = (p->n + 255) / 256 * 256;
+                        rc = mi_launch_dense_xl(c, p->xl_chunks, p->stream);
+                        break;
+                    }
                 }
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(p->ev1, p->stream));
+                return MI_OK;
+            };
+            if (p->opt_xl_async) {
+                p->last_R = R; p->last_offset = replica_offset; p->has_run = true;
+                p->worker = std::thread([p, cooling_run]() {
+                    g_kernel.clear(); g_err.clear();
+                    p->worker_rc = cooling_run();
+                    p->worker_err = g_err;
+                    p->worker_kernel = g_kernel;
+                });
+                return MI_OK;
             }
+            rc = cooling_run();
+            if (rc) return rc;
+            p->last_R = R; p->last_offset = replica_offset; p->has_run = true;
+            p->last_kernel = g_kernel;
+            return MI_OK;
         }
         if (rc) return rc;
         HIP_TRY(hipEventRecord(p->ev1, p->stream));
@@ -1171,6 +1225,7 @@ int mi_sa_tempering_begin(mi_sa_problem *p, const double *ladder_betas, int T, i
                           uint32_t first_replica, int R_local)
 {
     if (!p || !ladder_betas) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     if (T < 2 || T > 1024) return fail(MI_EINVAL, "a tempering ladder has 2 .. 1024 temperatures (got %d)", T);
     if (chains < 1) return fail(MI_EINVAL, "chains must be >= 1");
     const long long total = (long long)T * chains;
@@ -1213,6 +1268,7 @@ int mi_sa_tempering_begin(mi_sa_problem *p, const double *ladder_betas, int T, i
 
 static int tempering_exchange_impl(mi_sa_problem *p, uint32_t round, uint64_t seed, const double *all_energies, bool on_device)
 {
+    if (const int rc_w = settle(p)) return rc_w;
     if (!p) return fail(MI_EINVAL, "NULL problem");
     if (p->pt_T == 0) return fail(MI_ESTATE, "mi_sa_tempering_begin has not been called on this problem");
     if (!p->has_run || p->last_R != p->pt_R_local) return fail(MI_ESTATE, "no tempering round has run on this problem");
@@ -1249,6 +1305,7 @@ int mi_sa_tempering_exchange_dev(mi_sa_problem *p, uint32_t round, uint64_t seed
 int mi_sa_device_results(mi_sa_problem *p, void **out_d_states, double **out_d_energy, int *out_R)
 {
     if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (const int rc_w = settle(p)) return rc_w;
     if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1261,6 +1318,7 @@ int mi_sa_device_results(mi_sa_problem *p, void **out_d_states, double **out_d_e
 int mi_sa_tempering_state(mi_sa_problem *p, int32_t *out_rung, uint64_t *out_proposed, uint64_t *out_accepted)
 {
     if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (const int rc_w = settle(p)) return rc_w;
     if (p->pt_T == 0) return fail(MI_ESTATE, "mi_sa_tempering_begin has not been called on this problem");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1291,6 +1349,7 @@ int mi_sa_anneal(mi_sa_problem *p, int R, uint32_t replica_offset, int num_sweep
 int mi_sa_sync(mi_sa_problem *p)
 {
     if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (const int rc_w = settle(p)) return rc_w;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return MI_OK;
@@ -1299,6 +1358,7 @@ int mi_sa_sync(mi_sa_problem *p)
 int mi_sa_last_kernel_ms(mi_sa_problem *p, float *out_ms)
 {
     if (!p || !out_ms) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventSynchronize(p->ev1));
@@ -1309,6 +1369,7 @@ int mi_sa_last_kernel_ms(mi_sa_problem *p, float *out_ms)
 int mi_sa_last_launch_count(mi_sa_problem *p, int *out_launches)
 {
     if (!p || !out_launches) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
     *out_launches = p->last_launches;
     return MI_OK;
@@ -1317,6 +1378,7 @@ int mi_sa_last_launch_count(mi_sa_problem *p, int *out_launches)
 int mi_sa_last_kernel_name(mi_sa_problem *p, char *out, int len)
 {
     if (!p || !out || len < 1) return fail(MI_EINVAL, "NULL argument");
+    if (const int rc_w = settle(p)) return rc_w;
     if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
     snprintf(out, (size_t)len, "%s", p->last_kernel.c_str());
     return MI_OK;
@@ -1325,6 +1387,7 @@ int mi_sa_last_kernel_name(mi_sa_problem *p, char *out, int len)
 int mi_sa_fetch(mi_sa_problem *p, void *out_states, double *out_energy, uint64_t *out_stats)
 {
     if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (const int rc_w = settle(p)) return rc_w;
     if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1343,6 +1406,7 @@ int mi_sa_fetch(mi_sa_problem *p, void *out_states, double *out_energy, uint64_t
 int mi_sa_best(mi_sa_problem *p, int *out_index, double *out_energy, uint64_t *out_key, void *out_state)
 {
     if (!p) return fail(MI_EINVAL, "NULL problem");
+    if (const int rc_w = settle(p)) return rc_w;
     if (!p->has_run) return fail(MI_ESTATE, "no anneal has been run on this problem");
     HIP_TRY(hipSetDevice(p->device));
     unsigned long long init_key = ~0ull, key = 0;

@@ -279,7 +279,7 @@ def test_error_behaviour():
                        ("variant", 9)):
         with pytest.raises(_lib.MiSaError):
             p.set_option(key, value)
-    for key, value in (("xl_batched", 2), ("xl_chain", 2), ("xl_chain", 0), ("xl_chunk", 3), ("xl_cold_permille", 0)):
+    for key, value in (("xl_batched", 2), ("xl_chain", 2), ("xl_chain", 0), ("xl_chunk", 3), ("xl_cold_permille", 0), ("xl_async", 0)):
         p.set_option(key, value)
     p.close()
     assert b"" == b"" and lib.mi_last_error() is not None
@@ -468,6 +468,23 @@ def test_batched_dense_kernel_many_replicas_equal_workgroup_per_replica():
         assert "k_xg_chain" in name and "k_anneal_dense_xl" in name
         assert np.array_equal(got[0], ref[0]) and got[2]["accepted"] == ref[2]["accepted"]
         assert np.allclose(got[1], ref[1], rtol=1e-6)
+        # the hand-over is decided per chunk on the host -- by a worker thread of the problem, so the call returns at once
+        # (as every other anneal does); "xl_async" = 0 keeps it in the caller: same result, and the call takes the run's time
+        import time
+        p.set_option("xl_async", 0)
+        t0 = time.perf_counter()
+        p.anneal(R, cool, 9)
+        t_in_caller = time.perf_counter() - t0
+        in_caller = p.fetch()
+        p.set_option("xl_async", 1)
+        t0 = time.perf_counter()
+        p.anneal(R, cool, 9)
+        t_call = time.perf_counter() - t0
+        assert p.kernel_name() == name                        # (joins the worker)
+        again = p.fetch()
+        for other in (in_caller, again):
+            assert np.array_equal(other[0], ref[0]) and np.array_equal(other[1], got[1]) and other[2]["accepted"] == ref[2]["accepted"]
+        assert t_call < 0.5 * t_in_caller, (t_call, t_in_caller)
         p.set_option("xl_cold_permille", 0)                   # never hand over: K1g alone, same result
         p.anneal(R, cool, 9)
         assert "dense_xl" not in p.kernel_name()
