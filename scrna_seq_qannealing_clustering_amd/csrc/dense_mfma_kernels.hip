@@ -42,7 +42,7 @@
 #endif
 
 // diagnostic timing builds (-DMI_K1M_DEBUG; results are wrong): DenseArgs::debug bit0 = no ring DMA, bit2 = no
-// decision chain, bit3 = no MFMAs.  -DMI_K1M_TICKS: s_memtime phase counters of the wave `debug >> 8` in stats[4..13]
+// decision chain, bit3 = no MFMAs, bit5 = no hand-applied rows (diag_pre).  -DMI_K1M_TICKS: s_memtime phase counters of the wave `debug >> 8` in stats[4..13]
 // (per phase g: the rendezvous; operand reads; MFMA issue; what follows them -- printed by scripts/perf_k1m.py).
 #ifdef MI_K1M_DEBUG
 #define K1M_DBG(bit) ((a.debug & (bit)) != 0)
@@ -281,14 +281,25 @@ __global__ void __launch_bounds__(1024, 4) k_anneal_dense_mfma(DenseArgs a)
     };
     auto diag_pre = [&](int gb_cur, auto k0c, auto k1c) {
         constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+        if (K1M_DBG(32)) return;
         lds_f32 *Sp = opaque(Sbuf + (gb_cur & 1) * 256 + dr);
         lds_f32 *Ep = opaque(Ebuf + dq * 4);
+        // (the eight signs first, the coupling rows three LDS round trips deep: row by row with a full wait each, the
+        // piece was eight LDS latencies long -- and it is the owner that the other fifteen waves wait for)
+        float sv[K1 - K0];
         static_for<K0, K1>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const f32x4acc e4 = *(lds_f32x4 *)(Ep + k * 16);
-            const float sv = Sp[(k >> 2) * 64 + (k & 3) * 16];
+            sv[k - K0] = Sp[(k >> 2) * 64 + (k & 3) * 16];
+        });
+        f32x4acc e4[3];
+        e4[0] = *(lds_f32x4 *)(Ep + K0 * 16);
+        e4[1] = *(lds_f32x4 *)(Ep + (K0 + 1) * 16);
+        static_for<K0, K1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k + 2 < K1) e4[(k + 2 - K0) % 3] = *(lds_f32x4 *)(Ep + (k + 2) * 16);
+            const f32x4acc e = e4[(k - K0) % 3];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) d_tq[m] = __fmaf_rn(e4[m], sv, d_tq[m]);
+            for (int m = 0; m < 4; ++m) d_tq[m] = __fmaf_rn(e[m], sv[k - K0], d_tq[m]);
         });
     };
     auto diag_thresholds = [&](int nb) {
