@@ -56,6 +56,39 @@ __global__ void __launch_bounds__(1024) k_probe_class(unsigned long long *out, f
     }
 }
 
+// which waves share a SIMD with wave 0: a dependent v_fma chain on wave 0 beside ONE streaming wave `partner`
+__global__ void __launch_bounds__(1024) k_probe_partner(unsigned long long *out, float *sink, int partner)
+{
+    __shared__ volatile int done;
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        float f = 0.001f * lane;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        for (int k = 0; k < STEPS; ++k) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) asm volatile("v_fma_f32 %0, %0, %0, 0.5" : "+v"(f));
+        }
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) { out[blockIdx.x] = t1 - t0; done = 1; }
+        sink[threadIdx.x] = f;
+    } else if (wave == partner) {
+        f32x4 acc[8];
+        for (int k = 0; k < 8; ++k) acc[k] = f32x4{0, 0, 0, 0};
+        const float av = 0.001f * lane, bv = 1.0f;
+        while (!done) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[k], 0, 0, 0);
+        }
+        float s = 0.0f;
+        for (int k = 0; k < 8; ++k) for (int q = 0; q < 4; ++q) s += acc[k][q];
+        sink[threadIdx.x] = s;
+    }
+}
+
 template <int PRIO>
 __global__ void __launch_bounds__(1024) k_probe(unsigned long long *out, float *sink, int mfma_waves, int all_simds)
 {
@@ -136,5 +169,15 @@ int main()
             printf("%-36s beside %d streaming waves of its SIMD: %.1f ticks per instruction%s\n", names[kind], mw,
                    s / wgs / STEPS / 8, kind == 2 ? " pair" : "");
         }
+    for (int partner = 1; partner < 16; ++partner) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(k_probe_partner, dim3(wgs), dim3(1024), 0, 0, d_out, d_sink, partner);
+            CHECK(hipDeviceSynchronize());
+        }
+        CHECK(hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost));
+        double s = 0; for (int i = 0; i < wgs; ++i) s += (double)h[i];
+        printf("v_fma_f32 chain on wave 0 beside ONE streaming wave, wave %2d of the workgroup: %.1f ticks per instruction\n",
+               partner, s / wgs / STEPS / 8);
+    }
     return 0;
 }
